@@ -1,0 +1,131 @@
+/* pigs_hip.h -- C ABI of libpigs_hip.so: the MI355X (gfx950) drop-in for the PIGS
+ * action / energy hot path of amaciarey/PathIntegralGroundState.
+ *
+ * The reference has no FFI: its boundary is the Fortran procedure interface
+ * (SURVEY.md §8b).  Each entry point below names the reference procedure(s) it
+ * replaces (file:line under the reference tree).  A Fortran host binds these with
+ * ISO_C_BINDING (pathintegralgroundstate_amd/host/pigs_capi.f90).
+ *
+ * Conventions (identical to the reference so that a Fortran caller passes its arrays
+ * unchanged): fp64 everywhere; arrays column-major; Path(dim,Np,0:2*Nb); tables
+ * F(0:Nmax+1) with the pointer at element 0; particle indices ip are 1-BASED, bead
+ * indices ib 0-BASED, walker indices 0-based (walkers are new: the reference has one).
+ * Every function returns PIGS_OK (0) or a negative pigs_status; nothing calls exit/stop.
+ * A context is bound to one device and one stream; calls on one context must be
+ * serialized by the caller (one host thread per GPU); there is no global mutable state.
+ */
+#ifndef PIGS_HIP_H
+#define PIGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIGS_ABI_VERSION 1
+#define PIGS_MAXDIM 3
+
+typedef enum pigs_status {
+    PIGS_OK              = 0,
+    PIGS_ERR_ARG         = -1,  /* bad argument / out-of-range index               */
+    PIGS_ERR_HIP         = -2,  /* HIP runtime error (pigs_last_error has the text) */
+    PIGS_ERR_NO_DEVICE   = -3,  /* no gfx950 device visible                        */
+    PIGS_ERR_UNSUPPORTED = -4,  /* e.g. v_table=F with force terms (reference Q3)  */
+    PIGS_ERR_COMM        = -5   /* RCCL error                                      */
+} pigs_status;
+
+/* The module globals the reference hot path reads implicitly
+ * (global_mod.f90:5-12: dim,Np,Nb,Nmax,dr,rcut2,wf_table,v_table,Lbox,LboxHalf;
+ *  system_mod.f90:8-9: Rm,a_ho) plus dt, which the reference passes per call. */
+typedef struct pigs_params {
+    int32_t dim, Np, Nb, Nmax;
+    int32_t trap, wf_table, v_table, reserved;
+    double  dr, rcut2, dt, Rm;
+    double  Lbox[PIGS_MAXDIM];
+    double  a_ho[PIGS_MAXDIM];
+} pigs_params;
+
+typedef struct pigs_ctx pigs_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+/* Replaces the module-global set-up of vpi.f90:76-153 for the hot path: uploads both
+ * tables (built host-side by the caller exactly as vpi_mod.f90:84-145 builds them, or
+ * by pigs_build_tables) and reserves HBM for n_walkers resident worldlines. */
+int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *LogWF,
+                    int32_t n_walkers, int32_t device_id, pigs_ctx **out);
+int pigs_ctx_destroy(pigs_ctx *ctx);
+const char *pigs_last_error(void);
+int pigs_abi_version(void);
+int pigs_device_count(int32_t *n);
+/* Blocks until all work queued on the context's stream has finished. */
+int pigs_sync(pigs_ctx *ctx);
+/* The context's hipStream_t (as void*) so a host can order its own work against it. */
+int pigs_stream(pigs_ctx *ctx, void **hip_stream);
+
+/* Host-side table fill: JastrowTable / PotentialTable (vpi_mod.f90:84-145) over
+ * LogPsi / Potential (system_mod.f90:38-66,136-182), including dr = rmax/real(Nmax-1)
+ * and the ghost cells.  Arrays hold Nmax+2 doubles. */
+int pigs_build_tables(int32_t Nmax, double Rm, double rmax, double *VTable, double *LogWF,
+                      double *dr_out);
+
+/* ---- worldline residency (replaces the host array Path, vpi.f90:134) ------------ */
+int pigs_path_upload(pigs_ctx *ctx, int32_t walker, const double *Path);
+int pigs_path_download(pigs_ctx *ctx, int32_t walker, double *Path);
+/* all walkers back to back: Paths(dim,Np,0:2*Nb,n_walkers) */
+int pigs_path_upload_all(pigs_ctx *ctx, const double *Paths);
+int pigs_path_download_all(pigs_ctx *ctx, double *Paths);
+
+/* ---- K1: batched Delta S  (replaces the 24 `call UpdateAction` sites of vpi_mod.f90,
+ * i.e. UpdateAction/UpdatePot/UpdateWf, vpi_mod.f90:2491-2841, + GreenFunction opt 0,
+ * global_mod.f90:19-72) --------------------------------------------------------------
+ * Item i moves bead ib[i] of particle ip[i] of walker walker[i] from xold(:,i) to
+ * xnew(:,i); DeltaS[i] has exactly the semantics of UpdateAction's output.  Row ip of
+ * the resident slice is never read (the reference's aliasing contract).
+ * xnew/xold are (dim,n_items) column-major.  Host-pointer form: synchronous. */
+int pigs_delta_action_batch(pigs_ctx *ctx, int64_t n_items,
+                            const int32_t *walker, const int32_t *ip, const int32_t *ib,
+                            const double *xnew, const double *xold, double *DeltaS);
+/* Same with DEVICE pointers, asynchronous on the context's stream (inputs resident in HBM). */
+int pigs_delta_action_batch_dev(pigs_ctx *ctx, int64_t n_items,
+                                const int32_t *d_walker, const int32_t *d_ip, const int32_t *d_ib,
+                                const double *d_xnew, const double *d_xold, double *d_DeltaS);
+/* Test hook: the components UpdateAction combines (DeltaPot, DeltaF2, DeltaLogPsi), 3 per item. */
+int pigs_delta_action_parts(pigs_ctx *ctx, int64_t n_items,
+                            const int32_t *walker, const int32_t *ip, const int32_t *ib,
+                            const double *xnew, const double *xold, double *parts);
+
+/* ---- K5: commit (replaces `Path(k,ip,ib)=xnew(k)` on accept / OldChain restore, e.g.
+ * vpi_mod.f90:370-374,948,987-995) -------------------------------------------------- */
+int pigs_commit_beads(pigs_ctx *ctx, int64_t n, const int32_t *walker, const int32_t *ip,
+                      const int32_t *ib, const double *x /* (dim,n) */);
+/* Swap accept branch, vpi_mod.f90:2454-2464: exchange beads Nb..2Nb of particles iw, ik. */
+int pigs_swap_tails(pigs_ctx *ctx, int32_t walker, int32_t iw, int32_t ik);
+
+/* ---- K2/K3: estimator-side sums --------------------------------------------------- */
+/* PotentialEnergy (sample_mod.f90:13-150) on one resident slice (test hook). */
+int pigs_potential_energy_slice(pigs_ctx *ctx, int32_t walker, int32_t ib, int32_t want_F2,
+                                double *Pot, double *F2);
+/* ThermEnergy (sample_mod.f90:323-388) for walkers[0..n): E, Ec, Ep per walker.
+ * walkers == NULL means walkers 0..n-1. */
+int pigs_therm_energy_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers,
+                            double *E, double *Ec, double *Ep);
+/* ---- K4: LocalEnergy (sample_mod.f90:154-319) on slice ib (0 or 2*Nb in vpi.f90:443-444). */
+int pigs_local_energy_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t ib,
+                            double *E, double *Kin, double *Pot);
+
+/* ---- multi-GPU: block-estimator reduction (new) ------------------------ */
+/* RCCL communicator over `nranks` contexts.  Single-process form (one host thread per
+ * GPU, the Fortran host): pigs_comm_init_all.  Multi-process form: rank 0 obtains an id
+ * with pigs_comm_unique_id, distributes the 128 bytes out of band, every rank calls
+ * pigs_comm_init_rank. */
+int pigs_comm_unique_id(char id[128]);
+int pigs_comm_init_rank(pigs_ctx *ctx, int32_t nranks, int32_t rank, const char id[128]);
+int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks);
+/* Sum vec[0..n) (host memory, fp64) over all ranks, in place. */
+int pigs_estimators_allreduce(pigs_ctx *ctx, double *vec, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIGS_HIP_H */

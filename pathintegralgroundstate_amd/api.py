@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's procedure interface over the C ABI (include/pigs_hip.h).
+
+The reference boundary is the Fortran call interface: ``UpdateAction``
+(reference vpi_mod.f90:2491), ``PotentialEnergy`` / ``LocalEnergy`` / ``ThermEnergy``
+(reference sample_mod.f90:13,154,323).  :class:`PigsContext` exposes the same operations with
+the same argument meaning (ip 1-based, ib 0-based, arrays in the reference's column-major
+layout, i.e. numpy C-order ``(M, Np, dim)`` for ``Path(dim,Np,0:2*Nb)``), batched over walkers.
+All compute happens in ``libpigs_hip.so``; if that library or a GPU is missing every call
+raises :class:`PigsError` -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .system import SystemConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpigs_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+# every symbol include/pigs_hip.h declares
+ABI_SYMBOLS = [
+    "pigs_ctx_create", "pigs_ctx_destroy", "pigs_last_error", "pigs_abi_version",
+    "pigs_device_count", "pigs_sync", "pigs_stream", "pigs_build_tables",
+    "pigs_path_upload", "pigs_path_download", "pigs_path_upload_all", "pigs_path_download_all",
+    "pigs_delta_action_batch", "pigs_delta_action_batch_dev", "pigs_delta_action_parts",
+    "pigs_commit_beads", "pigs_swap_tails", "pigs_potential_energy_slice",
+    "pigs_therm_energy_batch", "pigs_local_energy_batch", "pigs_comm_unique_id",
+    "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
+]
+
+
+class PigsError(RuntimeError):
+    pass
+
+
+class PigsParams(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("Np", C.c_int32), ("Nb", C.c_int32), ("Nmax", C.c_int32),
+                ("trap", C.c_int32), ("wf_table", C.c_int32), ("v_table", C.c_int32),
+                ("reserved", C.c_int32),
+                ("dr", C.c_double), ("rcut2", C.c_double), ("dt", C.c_double), ("Rm", C.c_double),
+                ("Lbox", C.c_double * 3), ("a_ho", C.c_double * 3)]
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen libpigs_hip.so (built in-tree by pathintegralgroundstate_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise PigsError(
+            f"{path} is missing: build it with `python -m pathintegralgroundstate_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.pigs_last_error.restype = C.c_char_p
+    L.pigs_ctx_create.argtypes = [C.POINTER(PigsParams), _dp, _dp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.pigs_ctx_destroy.argtypes = [vp]
+    L.pigs_device_count.argtypes = [_ip]
+    L.pigs_sync.argtypes = [vp]
+    L.pigs_stream.argtypes = [vp, C.POINTER(vp)]
+    L.pigs_build_tables.argtypes = [C.c_int32, C.c_double, C.c_double, _dp, _dp, _dp]
+    L.pigs_path_upload.argtypes = [vp, C.c_int32, _dp]
+    L.pigs_path_download.argtypes = [vp, C.c_int32, _dp]
+    L.pigs_path_upload_all.argtypes = [vp, _dp]
+    L.pigs_path_download_all.argtypes = [vp, _dp]
+    L.pigs_delta_action_batch.argtypes = [vp, C.c_int64, _ip, _ip, _ip, _dp, _dp, _dp]
+    L.pigs_delta_action_parts.argtypes = [vp, C.c_int64, _ip, _ip, _ip, _dp, _dp, _dp]
+    L.pigs_delta_action_batch_dev.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.pigs_commit_beads.argtypes = [vp, C.c_int64, _ip, _ip, _ip, _dp]
+    L.pigs_swap_tails.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    L.pigs_potential_energy_slice.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
+    L.pigs_therm_energy_batch.argtypes = [vp, C.c_int32, _ip, _dp, _dp, _dp]
+    L.pigs_local_energy_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, _dp, _dp, _dp]
+    L.pigs_comm_unique_id.argtypes = [C.c_char_p]
+    L.pigs_comm_init_rank.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
+    L.pigs_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32]
+    L.pigs_estimators_allreduce.argtypes = [vp, _dp, C.c_int32]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if name != "pigs_last_error":
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _chk(L, rc, what):
+    if rc != 0:
+        raise PigsError(f"{what} failed (status {rc}): {L.pigs_last_error().decode(errors='replace')}")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def device_count():
+    L = load_library()
+    n = C.c_int32(0)
+    rc = L.pigs_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def build_tables(cfg: SystemConfig):
+    """PotentialTable / JastrowTable (reference vpi_mod.f90:84-145) on the host."""
+    L = load_library()
+    VT = np.zeros(cfg.Nmax + 2)
+    WF = np.zeros(cfg.Nmax + 2)
+    dr = C.c_double()
+    _chk(L, L.pigs_build_tables(cfg.Nmax, cfg.Rm, cfg.rcut, _d(VT), _d(WF), C.byref(dr)),
+         "pigs_build_tables")
+    assert dr.value == cfg.dr
+    return VT, WF
+
+
+class PigsContext:
+    """W resident walkers on one MI355X + the batched hot-path operations."""
+
+    def __init__(self, cfg: SystemConfig, VTable, LogWF, n_walkers=1, device_id=0):
+        self.L = load_library()
+        self.cfg = cfg
+        self.n_walkers = int(n_walkers)
+        p = PigsParams()
+        p.dim, p.Np, p.Nb, p.Nmax = cfg.dim, cfg.Np, cfg.Nb, cfg.Nmax
+        p.trap, p.wf_table, p.v_table = int(cfg.trap), int(cfg.wf_table), int(cfg.v_table)
+        p.dr, p.rcut2, p.dt, p.Rm = cfg.dr, cfg.rcut2, cfg.dt, cfg.Rm
+        for k in range(3):
+            p.Lbox[k] = cfg.Lbox[k]
+            p.a_ho[k] = cfg.a_ho[k]
+        self._VT = _f64(VTable)
+        self._WF = _f64(LogWF)
+        if self._VT.size != cfg.Nmax + 2 or self._WF.size != cfg.Nmax + 2:
+            raise PigsError("tables must hold Nmax+2 doubles (F(0:Nmax+1))")
+        h = C.c_void_p()
+        _chk(self.L, self.L.pigs_ctx_create(C.byref(p), _d(self._VT), _d(self._WF), self.n_walkers,
+                                            int(device_id), C.byref(h)), "pigs_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pigs_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- residency
+    def upload(self, walker, Path):
+        Path = _f64(Path)
+        assert Path.shape == self.cfg.path_shape, (Path.shape, self.cfg.path_shape)
+        _chk(self.L, self.L.pigs_path_upload(self.h, int(walker), _d(Path)), "pigs_path_upload")
+
+    def download(self, walker):
+        Path = np.empty(self.cfg.path_shape)
+        _chk(self.L, self.L.pigs_path_download(self.h, int(walker), _d(Path)), "pigs_path_download")
+        return Path
+
+    def upload_all(self, Paths):
+        Paths = _f64(Paths)
+        assert Paths.shape == (self.n_walkers,) + self.cfg.path_shape
+        _chk(self.L, self.L.pigs_path_upload_all(self.h, _d(Paths)), "pigs_path_upload_all")
+
+    def download_all(self):
+        Paths = np.empty((self.n_walkers,) + self.cfg.path_shape)
+        _chk(self.L, self.L.pigs_path_download_all(self.h, _d(Paths)), "pigs_path_download_all")
+        return Paths
+
+    def sync(self):
+        _chk(self.L, self.L.pigs_sync(self.h), "pigs_sync")
+
+    def stream(self):
+        s = C.c_void_p()
+        _chk(self.L, self.L.pigs_stream(self.h, C.byref(s)), "pigs_stream")
+        return s.value
+
+    # ---- K1
+    def delta_action_batch(self, walker, ip, ib, xnew, xold):
+        """DeltaS[i] of moving bead ib[i] of particle ip[i] (1-based) of walker[i] from xold[i]
+        to xnew[i]: UpdateAction's output (reference vpi_mod.f90:2491-2530) per item."""
+        walker, ip, ib = _i32(walker).ravel(), _i32(ip).ravel(), _i32(ib).ravel()
+        n = walker.size
+        xnew, xold = _f64(xnew).reshape(n, self.cfg.dim), _f64(xold).reshape(n, self.cfg.dim)
+        out = np.empty(n)
+        _chk(self.L, self.L.pigs_delta_action_batch(self.h, n, _i(walker), _i(ip), _i(ib), _d(xnew),
+                                                    _d(xold), _d(out)), "pigs_delta_action_batch")
+        return out
+
+    def delta_action_parts(self, walker, ip, ib, xnew, xold):
+        """(DeltaPot, DeltaF2, DeltaLogPsi) per item: UpdatePot / UpdateWf outputs."""
+        walker, ip, ib = _i32(walker).ravel(), _i32(ip).ravel(), _i32(ib).ravel()
+        n = walker.size
+        xnew, xold = _f64(xnew).reshape(n, self.cfg.dim), _f64(xold).reshape(n, self.cfg.dim)
+        out = np.empty((n, 3))
+        _chk(self.L, self.L.pigs_delta_action_parts(self.h, n, _i(walker), _i(ip), _i(ib), _d(xnew),
+                                                    _d(xold), _d(out)), "pigs_delta_action_parts")
+        return out
+
+    def delta_action_batch_dev(self, n, d_walker, d_ip, d_ib, d_xnew, d_xold, d_out):
+        """Device-pointer form (ints = raw device addresses), asynchronous on the context stream."""
+        _chk(self.L, self.L.pigs_delta_action_batch_dev(self.h, int(n), d_walker, d_ip, d_ib, d_xnew,
+                                                        d_xold, d_out), "pigs_delta_action_batch_dev")
+
+    # ---- K5
+    def commit_beads(self, walker, ip, ib, x):
+        walker, ip, ib = _i32(walker).ravel(), _i32(ip).ravel(), _i32(ib).ravel()
+        n = walker.size
+        x = _f64(x).reshape(n, self.cfg.dim)
+        _chk(self.L, self.L.pigs_commit_beads(self.h, n, _i(walker), _i(ip), _i(ib), _d(x)),
+             "pigs_commit_beads")
+
+    def swap_tails(self, walker, iw, ik):
+        _chk(self.L, self.L.pigs_swap_tails(self.h, int(walker), int(iw), int(ik)), "pigs_swap_tails")
+
+    # ---- K2..K4
+    def potential_energy_slice(self, walker, ib, want_F2=False):
+        p, f = C.c_double(), C.c_double()
+        _chk(self.L, self.L.pigs_potential_energy_slice(self.h, int(walker), int(ib), int(want_F2),
+                                                        C.byref(p), C.byref(f)),
+             "pigs_potential_energy_slice")
+        return p.value, f.value
+
+    def therm_energy_batch(self, walkers=None):
+        w = None if walkers is None else _i32(walkers).ravel()
+        n = self.n_walkers if w is None else w.size
+        E, Ec, Ep = np.empty(n), np.empty(n), np.empty(n)
+        _chk(self.L, self.L.pigs_therm_energy_batch(self.h, n, None if w is None else _i(w), _d(E),
+                                                    _d(Ec), _d(Ep)), "pigs_therm_energy_batch")
+        return E, Ec, Ep
+
+    def local_energy_batch(self, ib, walkers=None):
+        w = None if walkers is None else _i32(walkers).ravel()
+        n = self.n_walkers if w is None else w.size
+        E, K, P = np.empty(n), np.empty(n), np.empty(n)
+        _chk(self.L, self.L.pigs_local_energy_batch(self.h, n, None if w is None else _i(w), int(ib),
+                                                    _d(E), _d(K), _d(P)), "pigs_local_energy_batch")
+        return E, K, P
+
+    # ---- multi-GPU
+    def comm_init_rank(self, nranks, rank, unique_id: bytes):
+        _chk(self.L, self.L.pigs_comm_init_rank(self.h, nranks, rank, unique_id), "pigs_comm_init_rank")
+
+    def estimators_allreduce(self, vec):
+        vec = _f64(vec).copy()
+        _chk(self.L, self.L.pigs_estimators_allreduce(self.h, _d(vec), vec.size),
+             "pigs_estimators_allreduce")
+        return vec
+
+    # ---- reference-named single-call mirrors (argument meaning as in the reference) ----------
+    def UpdateAction(self, walker, ip, ib, xnew, xold):
+        """reference vpi_mod.f90:2491: DeltaS for one bead move."""
+        return float(self.delta_action_batch([walker], [ip], [ib], [xnew], [xold])[0])
+
+    def PotentialEnergy(self, walker, ib, want_F2=False):
+        """reference sample_mod.f90:13: (Pot, F2) of slice ib."""
+        return self.potential_energy_slice(walker, ib, want_F2)
+
+    def LocalEnergy(self, walker, ib):
+        """reference sample_mod.f90:154: (E, Kin, Pot) of slice ib."""
+        E, K, P = self.local_energy_batch(ib, [walker])
+        return float(E[0]), float(K[0]), float(P[0])
+
+    def ThermEnergy(self, walker):
+        """reference sample_mod.f90:323: (E, Ec, Ep) of one worldline."""
+        E, Ec, Ep = self.therm_energy_batch([walker])
+        return float(E[0]), float(Ec[0]), float(Ep[0])
+
+
+def comm_unique_id():
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    _chk(L, L.pigs_comm_unique_id(buf), "pigs_comm_unique_id")
+    return buf.raw

@@ -1,0 +1,455 @@
+// pigs_capi.hip -- the C ABI of include/pigs_hip.h over the gfx950 kernels.
+//
+// A context owns one device, one stream, the resident worldlines of its walkers (SoA
+// layout of pigs_device.h), both tables, and grow-only scratch buffers; nothing is
+// allocated inside the *_dev / launch paths (graph-capture safe).  There is NO CPU
+// fallback anywhere in this library: without a HIP device every call fails loudly.
+#include "../../include/pigs_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pigs_comm.h"
+#include "pigs_kernels.h"
+
+using namespace pigs;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(PIGS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct pigs_ctx {
+    pigs_params hp;
+    DevParams   P;
+    int         device    = 0;
+    int         n_walkers = 0;
+    hipStream_t stream    = nullptr;
+    double *d_paths = nullptr, *d_VT = nullptr, *d_WF = nullptr;
+    size_t  path_doubles = 0;        // resident doubles per walker (padded SoA)
+    size_t  raw_doubles  = 0;        // dim*Np*(2Nb+1): reference layout per walker
+    DevBuf<int32_t> d_walker, d_ip, d_ib, d_slotw, d_slotb;
+    DevBuf<double>  d_xnew, d_xold, d_out, d_parts, d_stage, d_slices, d_res;
+    pigs_comm  *comm = nullptr;
+};
+
+static int check_ctx(pigs_ctx *c)
+{
+    if (!c) return fail(PIGS_ERR_ARG, "null context");
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(PIGS_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+    return PIGS_OK;
+}
+
+extern "C" {
+
+const char *pigs_last_error(void) { return g_err; }
+int pigs_abi_version(void) { return PIGS_ABI_VERSION; }
+
+int pigs_device_count(int32_t *n)
+{
+    if (!n) return fail(PIGS_ERR_ARG, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(PIGS_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return PIGS_OK;
+}
+
+int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *LogWF,
+                    int32_t n_walkers, int32_t device_id, pigs_ctx **out)
+{
+    if (!p || !out) return fail(PIGS_ERR_ARG, "null pointer");
+    *out = nullptr;
+    if (p->dim < 1 || p->dim > PIGS_MAXDIM) return fail(PIGS_ERR_ARG, "dim=%d not in 1..3", p->dim);
+    if (p->Np < 2 || p->Nb < 1 || p->Nmax < 4 || n_walkers < 1)
+        return fail(PIGS_ERR_ARG, "bad sizes Np=%d Nb=%d Nmax=%d n_walkers=%d", p->Np, p->Nb, p->Nmax, n_walkers);
+    if (!(p->dr > 0.0) || !(p->dt > 0.0)) return fail(PIGS_ERR_ARG, "dr and dt must be positive");
+    // Reference quirk Q3: Force() is an empty stub, so the analytic (table-less) branch is
+    // unusable for the force terms; and the kernels consume tables only.
+    if (!p->v_table || !VTable) return fail(PIGS_ERR_UNSUPPORTED, "v_table=T with a VTable is mandatory (reference Force() is a stub)");
+    if (!p->wf_table || !LogWF) return fail(PIGS_ERR_UNSUPPORTED, "wf_table=T with a LogWF table is required by the GPU path");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(PIGS_ERR_NO_DEVICE, "no HIP device visible (%s); libpigs_hip has no CPU fallback",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(PIGS_ERR_ARG, "device_id=%d of %d", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+
+    pigs_ctx *c = new (std::nothrow) pigs_ctx();
+    if (!c) return fail(PIGS_ERR_ARG, "out of host memory");
+    c->hp = *p;
+    c->device = device_id;
+    c->n_walkers = n_walkers;
+    DevParams &P = c->P;
+    memset(&P, 0, sizeof P);
+    P.dim = p->dim; P.Np = p->Np; P.Nb = p->Nb; P.M = 2 * p->Nb + 1; P.Nmax = p->Nmax;
+    P.NpPad = (p->Np + 7) & ~7;
+    P.trap = p->trap; P.wf_table = p->wf_table; P.v_table = p->v_table; P.nW = n_walkers;
+    P.dr = p->dr; P.rcut2 = p->rcut2; P.dt = p->dt; P.Rm = p->Rm;
+    for (int k = 0; k < 3; ++k) {
+        P.Lbox[k]     = k < p->dim ? p->Lbox[k] : 1.0;
+        P.LboxHalf[k] = 0.5 * P.Lbox[k];                 // vpi.f90:118
+        P.a_ho[k]     = k < p->dim ? p->a_ho[k] : 1.0;
+    }
+    c->path_doubles = slice_doubles(P.dim, P.NpPad) * P.M;
+    c->raw_doubles  = (size_t)P.dim * P.Np * P.M;
+
+    int rc = PIGS_OK;
+    do {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        const size_t tb = (size_t)(p->Nmax + 2) * sizeof(double);
+        if (hipMalloc((void **)&c->d_VT, tb) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if (hipMalloc((void **)&c->d_WF, tb) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if (hipMalloc((void **)&c->d_paths, c->path_doubles * n_walkers * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if (hipMemcpy(c->d_VT, VTable, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if (hipMemcpy(c->d_WF, LogWF, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if (hipMemset(c->d_paths, 0, c->path_doubles * n_walkers * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+    } while (0);
+    if (rc != PIGS_OK) {
+        fail(rc, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        pigs_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return PIGS_OK;
+}
+
+int pigs_ctx_destroy(pigs_ctx *c)
+{
+    if (!c) return PIGS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { pigs_comm_destroy(c->comm); c->comm = nullptr; }
+    c->d_walker.release(); c->d_ip.release(); c->d_ib.release(); c->d_slotw.release(); c->d_slotb.release();
+    c->d_xnew.release(); c->d_xold.release(); c->d_out.release(); c->d_parts.release();
+    c->d_stage.release(); c->d_slices.release(); c->d_res.release();
+    if (c->d_paths) (void)hipFree(c->d_paths);
+    if (c->d_VT) (void)hipFree(c->d_VT);
+    if (c->d_WF) (void)hipFree(c->d_WF);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PIGS_OK;
+}
+
+int pigs_sync(pigs_ctx *c)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_stream(pigs_ctx *c, void **s)
+{
+    if (!c || !s) return fail(PIGS_ERR_ARG, "null pointer");
+    *s = (void *)c->stream;
+    return PIGS_OK;
+}
+
+// ---- residency -------------------------------------------------------------------------
+static int upload_range(pigs_ctx *c, int w0, int nw, const double *raw)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!raw) return fail(PIGS_ERR_ARG, "null Path");
+    if (w0 < 0 || nw < 1 || w0 + nw > c->n_walkers) return fail(PIGS_ERR_ARG, "walker range %d+%d of %d", w0, nw, c->n_walkers);
+    // stage in chunks of <= 64 walkers so the scratch stays small
+    const int chunk = 64;
+    for (int a = 0; a < nw; a += chunk) {
+        const int m = nw - a < chunk ? nw - a : chunk;
+        HIPCHK(c->d_stage.reserve(c->raw_doubles * m));
+        HIPCHK(hipMemcpyAsync(c->d_stage.p, raw + c->raw_doubles * a, c->raw_doubles * m * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+        HIPCHK(launch_pack(c->P, c->d_paths, c->d_stage.p, w0 + a, m, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return PIGS_OK;
+}
+
+static int download_range(pigs_ctx *c, int w0, int nw, double *raw)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!raw) return fail(PIGS_ERR_ARG, "null Path");
+    if (w0 < 0 || nw < 1 || w0 + nw > c->n_walkers) return fail(PIGS_ERR_ARG, "walker range %d+%d of %d", w0, nw, c->n_walkers);
+    const int chunk = 64;
+    for (int a = 0; a < nw; a += chunk) {
+        const int m = nw - a < chunk ? nw - a : chunk;
+        HIPCHK(c->d_stage.reserve(c->raw_doubles * m));
+        HIPCHK(launch_unpack(c->P, c->d_paths, c->d_stage.p, w0 + a, m, c->stream));
+        HIPCHK(hipMemcpyAsync(raw + c->raw_doubles * a, c->d_stage.p, c->raw_doubles * m * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return PIGS_OK;
+}
+
+int pigs_path_upload(pigs_ctx *c, int32_t walker, const double *Path) { return upload_range(c, walker, 1, Path); }
+int pigs_path_download(pigs_ctx *c, int32_t walker, double *Path) { return download_range(c, walker, 1, Path); }
+int pigs_path_upload_all(pigs_ctx *c, const double *Paths) { return c ? upload_range(c, 0, c->n_walkers, Paths) : fail(PIGS_ERR_ARG, "null context"); }
+int pigs_path_download_all(pigs_ctx *c, double *Paths) { return c ? download_range(c, 0, c->n_walkers, Paths) : fail(PIGS_ERR_ARG, "null context"); }
+
+// ---- K1 ----------------------------------------------------------------------------------
+static int check_items(pigs_ctx *c, int64_t n, const int32_t *walker, const int32_t *ip, const int32_t *ib)
+{
+    if (n < 0 || n > 0x7fffffff) return fail(PIGS_ERR_ARG, "n_items=%lld out of range", (long long)n);
+    if (n && (!walker || !ip || !ib)) return fail(PIGS_ERR_ARG, "null index array");
+    for (int64_t i = 0; i < n; ++i) {
+        if (walker[i] < 0 || walker[i] >= c->n_walkers || ip[i] < 1 || ip[i] > c->P.Np || ib[i] < 0 || ib[i] >= c->P.M)
+            return fail(PIGS_ERR_ARG, "item %lld: walker=%d ip=%d ib=%d out of range", (long long)i, walker[i], ip[i], ib[i]);
+    }
+    return PIGS_OK;
+}
+
+static int delta_action_host(pigs_ctx *c, int64_t n, const int32_t *walker, const int32_t *ip,
+                             const int32_t *ib, const double *xnew, const double *xold,
+                             double *DeltaS, double *parts)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    rc = check_items(c, n, walker, ip, ib); if (rc) return rc;
+    if (n == 0) return PIGS_OK;
+    if (!xnew || !xold || (!DeltaS && !parts)) return fail(PIGS_ERR_ARG, "null pointer");
+    const size_t nd = (size_t)n * c->P.dim;
+    HIPCHK(c->d_walker.reserve(n)); HIPCHK(c->d_ip.reserve(n)); HIPCHK(c->d_ib.reserve(n));
+    HIPCHK(c->d_xnew.reserve(nd)); HIPCHK(c->d_xold.reserve(nd)); HIPCHK(c->d_out.reserve(n));
+    if (parts) HIPCHK(c->d_parts.reserve((size_t)n * 3));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_walker.p, walker, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_ip.p, ip, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_xnew.p, xnew, nd * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_xold.p, xold, nd * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_delta_action(c->P, c->d_paths, c->d_VT, c->d_WF, (int)n, c->d_walker.p, c->d_ip.p,
+                               c->d_ib.p, c->d_xnew.p, c->d_xold.p, c->d_out.p,
+                               parts ? c->d_parts.p : nullptr, s));
+    if (DeltaS) HIPCHK(hipMemcpyAsync(DeltaS, c->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (parts) HIPCHK(hipMemcpyAsync(parts, c->d_parts.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PIGS_OK;
+}
+
+int pigs_delta_action_batch(pigs_ctx *c, int64_t n, const int32_t *walker, const int32_t *ip,
+                            const int32_t *ib, const double *xnew, const double *xold, double *DeltaS)
+{
+    if (!DeltaS && n) return fail(PIGS_ERR_ARG, "null DeltaS");
+    return delta_action_host(c, n, walker, ip, ib, xnew, xold, DeltaS, nullptr);
+}
+
+int pigs_delta_action_parts(pigs_ctx *c, int64_t n, const int32_t *walker, const int32_t *ip,
+                            const int32_t *ib, const double *xnew, const double *xold, double *parts)
+{
+    if (!parts && n) return fail(PIGS_ERR_ARG, "null parts");
+    return delta_action_host(c, n, walker, ip, ib, xnew, xold, nullptr, parts);
+}
+
+int pigs_delta_action_batch_dev(pigs_ctx *c, int64_t n, const int32_t *d_walker, const int32_t *d_ip,
+                                const int32_t *d_ib, const double *d_xnew, const double *d_xold,
+                                double *d_DeltaS)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffff) return fail(PIGS_ERR_ARG, "n_items=%lld out of range", (long long)n);
+    if (n == 0) return PIGS_OK;
+    if (!d_walker || !d_ip || !d_ib || !d_xnew || !d_xold || !d_DeltaS) return fail(PIGS_ERR_ARG, "null device pointer");
+    // indices are range-checked on the device (out-of-range items produce NaN, never a fault)
+    HIPCHK(launch_delta_action(c->P, c->d_paths, c->d_VT, c->d_WF, (int)n, d_walker, d_ip, d_ib,
+                               d_xnew, d_xold, d_DeltaS, nullptr, c->stream));
+    return PIGS_OK;
+}
+
+// ---- K5 ----------------------------------------------------------------------------------
+int pigs_commit_beads(pigs_ctx *c, int64_t n, const int32_t *walker, const int32_t *ip,
+                      const int32_t *ib, const double *x)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    rc = check_items(c, n, walker, ip, ib); if (rc) return rc;
+    if (n == 0) return PIGS_OK;
+    if (!x) return fail(PIGS_ERR_ARG, "null x");
+    const size_t nd = (size_t)n * c->P.dim;
+    HIPCHK(c->d_walker.reserve(n)); HIPCHK(c->d_ip.reserve(n)); HIPCHK(c->d_ib.reserve(n));
+    HIPCHK(c->d_xnew.reserve(nd));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_walker.p, walker, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_ip.p, ip, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_xnew.p, x, nd * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_commit_beads(c->P, c->d_paths, n, c->d_walker.p, c->d_ip.p, c->d_ib.p, c->d_xnew.p, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PIGS_OK;
+}
+
+int pigs_swap_tails(pigs_ctx *c, int32_t walker, int32_t iw, int32_t ik)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (walker < 0 || walker >= c->n_walkers || iw < 1 || iw > c->P.Np || ik < 1 || ik > c->P.Np)
+        return fail(PIGS_ERR_ARG, "swap_tails(walker=%d, iw=%d, ik=%d) out of range", walker, iw, ik);
+    if (iw == ik) return PIGS_OK;
+    HIPCHK(launch_swap_tails(c->P, c->d_paths, walker, iw, ik, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+// ---- K2/K3 -------------------------------------------------------------------------------
+int pigs_potential_energy_slice(pigs_ctx *c, int32_t walker, int32_t ib, int32_t want_F2,
+                                double *Pot, double *F2)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!Pot) return fail(PIGS_ERR_ARG, "null Pot");
+    if (walker < 0 || walker >= c->n_walkers || ib < 0 || ib >= c->P.M) return fail(PIGS_ERR_ARG, "walker=%d ib=%d out of range", walker, ib);
+    HIPCHK(c->d_slotw.reserve(1)); HIPCHK(c->d_slotb.reserve(1)); HIPCHK(c->d_slices.reserve(3));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slotw.p, &walker, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_slotb.p, &ib, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, 1, c->d_slotw.p, c->d_slotb.p, want_F2 ? 2 : 0, 0, c->d_slices.p, s));
+    double h[3];
+    HIPCHK(hipMemcpyAsync(h, c->d_slices.p, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *Pot = h[0];
+    if (F2) *F2 = want_F2 ? h[1] : 0.0;
+    return PIGS_OK;
+}
+
+int pigs_therm_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, double *E, double *Ec, double *Ep)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || (n > c->n_walkers && !walkers)) return fail(PIGS_ERR_ARG, "n=%d walkers", n);
+    if (n == 0) return PIGS_OK;
+    if (!E || !Ec || !Ep) return fail(PIGS_ERR_ARG, "null output");
+    const int ns = 2 * c->P.Nb;                       // slices 0..2Nb-1 (Q8)
+    std::vector<int32_t> sw((size_t)n * ns), sb((size_t)n * ns);
+    for (int i = 0; i < n; ++i) {
+        const int w = walkers ? walkers[i] : i;
+        if (w < 0 || w >= c->n_walkers) return fail(PIGS_ERR_ARG, "walker %d out of range", w);
+        for (int b = 0; b < ns; ++b) { sw[(size_t)i * ns + b] = w; sb[(size_t)i * ns + b] = b; }
+    }
+    const size_t nslot = (size_t)n * ns;
+    HIPCHK(c->d_slotw.reserve(nslot)); HIPCHK(c->d_slotb.reserve(nslot));
+    HIPCHK(c->d_slices.reserve(nslot * 3)); HIPCHK(c->d_res.reserve((size_t)n * 3));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slotw.p, sw.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_slotb.p, sb.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, (int)nslot, c->d_slotw.p, c->d_slotb.p, 1, 1, c->d_slices.p, s));
+    HIPCHK(launch_therm_combine(c->P, n, c->d_slices.p, c->d_res.p, c->d_res.p + n, c->d_res.p + 2 * (size_t)n, s));
+    HIPCHK(hipMemcpyAsync(E, c->d_res.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Ec, c->d_res.p + n, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Ep, c->d_res.p + 2 * (size_t)n, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));   // sw/sb must outlive the async copies
+    return PIGS_OK;
+}
+
+// ---- K4 ----------------------------------------------------------------------------------
+int pigs_local_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, int32_t ib,
+                            double *E, double *Kin, double *Pot)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0) return fail(PIGS_ERR_ARG, "n=%d", n);
+    if (n == 0) return PIGS_OK;
+    if (!E || !Kin || !Pot) return fail(PIGS_ERR_ARG, "null output");
+    if (ib < 0 || ib >= c->P.M) return fail(PIGS_ERR_ARG, "ib=%d out of range", ib);
+    std::vector<int32_t> sw(n);
+    for (int i = 0; i < n; ++i) {
+        sw[i] = walkers ? walkers[i] : i;
+        if (sw[i] < 0 || sw[i] >= c->n_walkers) return fail(PIGS_ERR_ARG, "walker %d out of range", sw[i]);
+    }
+    HIPCHK(c->d_slotw.reserve(n)); HIPCHK(c->d_res.reserve((size_t)n * 3));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slotw.p, sw.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_local_energy(c->P, c->d_paths, c->d_VT, c->d_WF, n, c->d_slotw.p, ib, c->d_res.p, s));
+    std::vector<double> h((size_t)n * 3);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_res.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) { E[i] = h[3 * i]; Kin[i] = h[3 * i + 1]; Pot[i] = h[3 * i + 2]; }
+    return PIGS_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------
+int pigs_comm_unique_id(char id[128])
+{
+    if (!id) return fail(PIGS_ERR_ARG, "null id");
+    const char *err = pigs_comm_get_unique_id(id);
+    return err ? fail(PIGS_ERR_COMM, "%s", err) : PIGS_OK;
+}
+
+int pigs_comm_init_rank(pigs_ctx *c, int32_t nranks, int32_t rank, const char id[128])
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(PIGS_ERR_ARG, "bad rank %d/%d", rank, nranks);
+    if (c->comm) { pigs_comm_destroy(c->comm); c->comm = nullptr; }
+    const char *err = pigs_comm_create_rank(&c->comm, nranks, rank, id);
+    return err ? fail(PIGS_ERR_COMM, "%s", err) : PIGS_OK;
+}
+
+int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks)
+{
+    if (!ctxs || nranks < 1) return fail(PIGS_ERR_ARG, "bad arguments");
+    std::vector<int> devs(nranks);
+    std::vector<pigs_comm *> comms(nranks, nullptr);
+    for (int i = 0; i < nranks; ++i) {
+        if (!ctxs[i]) return fail(PIGS_ERR_ARG, "null context %d", i);
+        devs[i] = ctxs[i]->device;
+    }
+    const char *err = pigs_comm_create_all(comms.data(), nranks, devs.data());
+    if (err) return fail(PIGS_ERR_COMM, "%s", err);
+    for (int i = 0; i < nranks; ++i) {
+        if (ctxs[i]->comm) pigs_comm_destroy(ctxs[i]->comm);
+        ctxs[i]->comm = comms[i];
+    }
+    return PIGS_OK;
+}
+
+int pigs_estimators_allreduce(pigs_ctx *c, double *vec, int32_t n)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || (n && !vec)) return fail(PIGS_ERR_ARG, "bad vector");
+    if (n == 0) return PIGS_OK;
+    if (!c->comm) return fail(PIGS_ERR_COMM, "no communicator: call pigs_comm_init_rank / pigs_comm_init_all first");
+    HIPCHK(c->d_res.reserve(n));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_res.p, vec, n * sizeof(double), hipMemcpyHostToDevice, s));
+    const char *err = pigs_comm_allreduce_sum_f64(c->comm, c->d_res.p, n, s);
+    if (err) return fail(PIGS_ERR_COMM, "%s", err);
+    HIPCHK(hipMemcpyAsync(vec, c->d_res.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PIGS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,39 @@
+// pigs_kernels.h -- host-callable launchers of the gfx950 kernels (pigs_kernels.hip).
+// All launches are asynchronous on the given stream and allocate nothing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pigs_device.h"
+
+namespace pigs {
+
+hipError_t launch_delta_action(const DevParams &P, const double *paths, const double *VT,
+                               const double *WF, int n_items, const int32_t *walker,
+                               const int32_t *ip, const int32_t *ib, const double *xnew,
+                               const double *xold, double *out, double *parts, hipStream_t st);
+
+hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT,
+                               int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
+                               int force_mode, int want_spring, double *out, hipStream_t st);
+
+hipError_t launch_therm_combine(const DevParams &P, int n, const double *slices, double *E,
+                                double *Ec, double *Ep, hipStream_t st);
+
+hipError_t launch_local_energy(const DevParams &P, const double *paths, const double *VT,
+                               const double *WF, int n_slots, const int32_t *slot_walker, int ib,
+                               double *out, hipStream_t st);
+
+hipError_t launch_commit_beads(const DevParams &P, double *paths, int64_t n, const int32_t *walker,
+                               const int32_t *ip, const int32_t *ib, const double *x, hipStream_t st);
+
+hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int iw, int ik,
+                             hipStream_t st);
+
+hipError_t launch_pack(const DevParams &P, double *paths, const double *raw, int w0, int nw,
+                       hipStream_t st);
+hipError_t launch_unpack(const DevParams &P, const double *paths, double *raw, int w0, int nw,
+                         hipStream_t st);
+
+} // namespace pigs

@@ -1,0 +1,520 @@
+// pigs_kernels.hip -- hand-written gfx950 kernels of the PIGS action / energy hot path.
+//
+//   K1  k_delta_action   batched Delta S of proposal beads      (vpi_mod.f90:2491-2841)
+//   K2  k_slice_energy   per-slice V, sum_i|F_i|^2 (+ K3 spring) (sample_mod.f90:13-150,359-380)
+//   K3' k_therm_combine  Chin-weighted combine per walker        (sample_mod.f90:344-385)
+//   K4  k_local_energy   Jastrow local energy of one slice       (sample_mod.f90:154-319)
+//   K5  k_commit_beads / k_swap_tails                            (vpi_mod.f90:370-374,2454-2464)
+//   layout kernels k_pack / k_unpack between the reference's Path(dim,Np,0:2Nb) and the
+//   resident SoA layout (pigs_device.h).
+//
+// Compile with -ffp-contract=off (per-term bit parity with the reference, see pigs_device.h).
+#include "pigs_device.h"
+#include "pigs_kernels.h"
+
+namespace pigs {
+
+// =====================================================================================
+// K1: one wave64 per proposal item; lane l visits partners jp = l, l+64, ... of the
+// item's slice (unit-stride 512-B loads per coordinate), accumulates its partial sums
+// in registers, then one butterfly per accumulator.  Wave-uniform control flow per item
+// (bead parity / end bead), so no divergence except the physical cutoff test.
+// Algorithmic bytes per item: dim*Np*8 (slice) + 2*dim*8 (xnew,xold) + 8 (DeltaS)
+// (+12 B of indices), i.e. 6 200 B at Np=256 for Np-1=255 bead-pair evaluations.
+// =====================================================================================
+template <int DIM, bool TRAP>
+__global__ __launch_bounds__(256) void k_delta_action(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = threadIdx.x >> 6;
+    const int nwave = gridDim.x * (blockDim.x >> 6);
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+
+    for (int item = blockIdx.x * (blockDim.x >> 6) + wid; item < n_items; item += nwave) {
+        const int it = __builtin_amdgcn_readfirstlane(item);
+        const int w  = walker[it];
+        const int p  = ipv[it] - 1;          // 0-based moved particle
+        const int b  = ibv[it];
+        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
+            if (lane == 0) out[it] = __builtin_nan("");      // bad index: never touch memory with it
+            continue;
+        }
+        double xn[DIM], xo[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xn[k] = xnew[(size_t)it * DIM + k];
+            xo[k] = xold[(size_t)it * DIM + k];
+        }
+        const double *S   = paths + ((size_t)w * P.M + b) * sl;
+        const bool odd    = (b & 1) != 0;                    // UpdateAction: force term on odd beads
+        const bool endb   = (b == 0) || (b == 2 * P.Nb);     // UpdateWf only on the two end beads
+
+        double potN = 0.0, potO = 0.0, psiN = 0.0, psiO = 0.0;
+        double fN[DIM], fO[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { fN[k] = 0.0; fO[k] = 0.0; }
+
+        if (TRAP && lane == 0) {                              // vpi_mod.f90:2688-2695, 2555-2560
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                potN = potN + trap_pot(0, P.a_ho[k], xn[k]);
+                potO = potO + trap_pot(0, P.a_ho[k], xo[k]);
+                fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
+                fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
+                if (endb) {
+                    psiO = psiO + trap_psi(0, P.a_ho[k], xo[k]);
+                    psiN = psiN + trap_psi(0, P.a_ho[k], xn[k]);
+                }
+            }
+        }
+
+        for (int j0 = 0; j0 < P.Np; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < P.Np && j != p) {                        // vpi_mod.f90:2699: never read row ip
+                double dnew[DIM], dold[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                    const double rj = S[(size_t)k * P.NpPad + j];
+                    dnew[k] = xn[k] - rj;                      // :2706
+                    dold[k] = xo[k] - rj;                      // :2707
+                }
+                double r2n, r2o;
+                if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+                else      { r2o = min_image<DIM>(dold, P); r2n = min_image<DIM>(dnew, P); }
+
+                if (TRAP || r2n <= P.rcut2) {                // :2723 (Q5) / :2771
+                    const double r = sqrt(r2n);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    potN = potN + interp0(VT, L, P.dr);
+                    if (odd) {
+                        const double dv = interp1(VT, L, P.dr);
+#pragma unroll
+                        for (int k = 0; k < DIM; ++k) fN[k] = fN[k] + dv * dnew[k] / r;   // :2784
+                    }
+                    if (endb) psiN = psiN + interp0(WF, L, P.dr);                       // :2638
+                }
+                if (r2o <= P.rcut2) {                        // :2745 / :2795
+                    const double r = sqrt(r2o);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    potO = potO + interp0(VT, L, P.dr);
+                    if (odd) {
+                        const double dv = interp1(VT, L, P.dr);
+#pragma unroll
+                        for (int k = 0; k < DIM; ++k) fO[k] = fO[k] + dv * dold[k] / r;   // :2808
+                    }
+                    if (endb) psiO = psiO + interp0(WF, L, P.dr);                       // :2624
+                } else if (TRAP && endb) {
+                    // UpdateWf's trap branch has no cutoff on either distance (vpi_mod.f90:2595-2615)
+                    const double r = sqrt(r2o);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    psiO = psiO + interp0(WF, L, P.dr);
+                }
+            }
+        }
+
+        potN = wave_sum(potN);
+        potO = wave_sum(potO);
+        double dF2 = 0.0, dPsi = 0.0;
+        if (odd) {
+            double fn2 = 0.0, fo2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                const double a = wave_sum(fN[k]);
+                const double c = wave_sum(fO[k]);
+                fn2 = fn2 + a * a;                            // :2831
+                fo2 = fo2 + c * c;                            // :2832
+            }
+            dF2 = fn2 - fo2;                                  // :2835
+        }
+        if (endb) {
+            psiN = wave_sum(psiN);
+            psiO = wave_sum(psiO);
+            dPsi = psiN - psiO;                               // :2653
+        }
+        if (lane == 0) {
+            const double dPot = potN - potO;                  // :2838
+            out[it] = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527
+            if (parts) {
+                parts[(size_t)it * 3 + 0] = dPot;
+                parts[(size_t)it * 3 + 1] = dF2;
+                parts[(size_t)it * 3 + 2] = dPsi;
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// K2 (+K3): one workgroup per (walker, slice).  The slice is staged once in LDS (SoA);
+// thread i owns particle i and walks every partner j != i (LDS broadcast reads), so the
+// full force vector F_i stays in registers and no antisymmetric scatter / atomics are
+// needed.  Each pair is visited from both sides: V counts half from each side
+// (multiplying by 0.5 is exact), f_ji = -f_ij exactly (the wrap is odd-symmetric).
+// Optional spring term of ThermEnergy between slice ib and ib+1 (sample_mod.f90:359-380).
+// out[3*slot+0..2] = Pot, F2 (0 if !want_f2), spring sum.
+// =====================================================================================
+template <int DIM, bool TRAP>
+__global__ __launch_bounds__(256) void k_slice_energy(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
+    int n_slots, const int32_t *__restrict__ slot_walker, const int32_t *__restrict__ slot_ib,
+    int force_mode /* 0 never, 1 odd beads, 2 always */, int want_spring,
+    double *__restrict__ out)
+{
+    extern __shared__ double lds[];
+    double *sx  = lds;                       // DIM * NpPad doubles
+    double *red = lds + DIM * P.NpPad;       // 3 * (blockDim/64) doubles
+
+    const int slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    const int w  = slot_walker[slot];
+    const int b  = slot_ib[slot];
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+    const double *S = paths + ((size_t)w * P.M + b) * sl;
+    const bool want_f = force_mode == 2 || (force_mode == 1 && (b & 1));
+
+    for (int t = threadIdx.x; t < DIM * P.NpPad; t += blockDim.x) sx[t] = S[t];
+    __syncthreads();
+
+    double pot = 0.0, f2 = 0.0, spring = 0.0;
+    for (int i = threadIdx.x; i < P.Np; i += blockDim.x) {
+        double xi[DIM], F[DIM];
+        double poti = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xi[k] = sx[k * P.NpPad + i];
+            F[k]  = 0.0;
+            if (TRAP) {                                       // sample_mod.f90:33-42
+                F[k] = trap_pot(1, P.a_ho[k], xi[k]);
+                pot  = pot + trap_pot(0, P.a_ho[k], xi[k]);
+            }
+        }
+        for (int j = 0; j < P.Np; ++j) {
+            if (j == i) continue;
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];   // :51
+            const double r2 = TRAP ? plain_r2<DIM>(d) : min_image<DIM>(d, P);
+            if (TRAP || r2 <= P.rcut2) {                      // :64 / :98
+                const double r = sqrt(r2);
+                const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                poti = poti + interp0(VT, L, P.dr);
+                if (want_f) {
+                    const double dv = interp1(VT, L, P.dr);
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) F[k] = F[k] + dv * d[k] / r;  // :113-114
+                }
+            }
+        }
+        pot = pot + 0.5 * poti;
+        if (want_f) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) f2 = f2 + F[k] * F[k];                // :143
+        }
+        if (want_spring) {                                    // sample_mod.f90:359-380 (Q8)
+            const double *S1 = S + sl;
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = xi[k] - S1[(size_t)k * P.NpPad + i];
+            const double r2 = TRAP ? plain_r2<DIM>(d) : min_image<DIM>(d, P);
+            if (TRAP || r2 <= P.rcut2) spring = spring + 0.5 * r2 / (P.dt * P.dt);
+        }
+    }
+
+    pot = wave_sum(pot); f2 = wave_sum(f2); spring = wave_sum(spring);
+    const int nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wid] = pot; red[nw + wid] = f2; red[2 * nw + wid] = spring; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0, e = 0.0;
+        for (int q = 0; q < nw; ++q) { a += red[q]; c += red[nw + q]; e += red[2 * nw + q]; }
+        out[(size_t)slot * 3 + 0] = a;
+        out[(size_t)slot * 3 + 1] = want_f ? c : 0.0;
+        out[(size_t)slot * 3 + 2] = e;
+    }
+}
+
+// K3': ThermEnergy's slice loop for one walker per thread, in the reference's slice
+// order (sample_mod.f90:344-385).  slices[(i*2Nb + ib)*3 + {0,1,2}] from k_slice_energy.
+__global__ void k_therm_combine(DevParams P, int n, const double *__restrict__ slices,
+                                double *__restrict__ E, double *__restrict__ Ec, double *__restrict__ Ep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ns = 2 * P.Nb;
+    double e = 0.0, ep = 0.0;
+    for (int ib = 0; ib < ns; ++ib) {                         // :344 (slice 2Nb skipped, Q8)
+        const double pot = slices[((size_t)i * ns + ib) * 3 + 0];
+        const double f2  = slices[((size_t)i * ns + ib) * 3 + 1];
+        const double sp  = slices[((size_t)i * ns + ib) * 3 + 2];
+        if (ib == P.Nb) ep = pot;                             // :353
+        e = e + green_function(1, ib, P.Nb, P.dt, pot, f2);   // :357
+        e = e - sp;                                           // :374/:377 summed per slice
+    }
+    e = 0.5 * (e / (double)(float)P.Nb + (double)(float)(P.dim * P.Np) / P.dt);   // :384
+    E[i]  = e;
+    Ec[i] = e - ep;                                           // :385
+    Ep[i] = ep;
+}
+
+// =====================================================================================
+// K4: LocalEnergy of the Jastrow trial function on one slice per workgroup
+// (sample_mod.f90:154-319): thread i owns particle i (drift F_i in registers), pair
+// terms LapLogPsi / Pot are counted from both sides and halved.
+// out[3*slot+0..2] = E, Kin, Pot.
+// =====================================================================================
+template <int DIM, bool TRAP>
+__global__ __launch_bounds__(256) void k_local_energy(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
+    const double *__restrict__ WF, int n_slots, const int32_t *__restrict__ slot_walker, int ib,
+    double *__restrict__ out)
+{
+    extern __shared__ double lds[];
+    double *sx  = lds;
+    double *red = lds + DIM * P.NpPad;
+
+    const int slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    const int w = slot_walker ? slot_walker[slot] : slot;
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+    const double *S = paths + ((size_t)w * P.M + ib) * sl;
+    const double dimm1 = (double)((float)DIM - 1.0f);         // (real(dim)-1), :280
+
+    for (int t = threadIdx.x; t < DIM * P.NpPad; t += blockDim.x) sx[t] = S[t];
+    __syncthreads();
+
+    double pot = 0.0, lap = 0.0, lap1 = 0.0, f2 = 0.0;
+    for (int i = threadIdx.x; i < P.Np; i += blockDim.x) {
+        double xi[DIM], F[DIM];
+        double poti = 0.0, lapi = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xi[k] = sx[k * P.NpPad + i];
+            F[k]  = 0.0;
+            if (TRAP) {                                       // :177-187
+                F[k] = trap_psi(1, P.a_ho[k], xi[k]);
+                pot  = pot + trap_pot(0, P.a_ho[k], xi[k]);
+                lap1 = lap1 + trap_psi(2, P.a_ho[k], xi[k]);
+            }
+        }
+        for (int j = 0; j < P.Np; ++j) {
+            if (j == i) continue;
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
+            const double r2 = TRAP ? plain_r2<DIM>(d) : min_image<DIM>(d, P);
+            if (TRAP || r2 <= P.rcut2) {                      // :230 / :264
+                const double r = sqrt(r2);
+                const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                const double dudr   = interp1(WF, L, P.dr);   // :270
+                const double d2udr2 = interp2(WF, L, P.dr);   // :271
+                lapi = lapi + (dimm1 * dudr / r + d2udr2);    // :280
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) F[k] = F[k] + dudr * d[k] / r;   // :283-284
+                poti = poti + interp0(VT, L, P.dr);           // :291
+            }
+        }
+        pot = pot + 0.5 * poti;
+        lap = lap + 0.5 * lapi;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) f2 = f2 + F[k] * F[k];  // :309
+    }
+
+    pot = wave_sum(pot); lap = wave_sum(lap); lap1 = wave_sum(lap1); f2 = wave_sum(f2);
+    const int nw = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wid] = pot; red[nw + wid] = lap; red[2 * nw + wid] = lap1; red[3 * nw + wid] = f2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, l = 0.0, l1 = 0.0, c = 0.0;
+        for (int q = 0; q < nw; ++q) { a += red[q]; l += red[nw + q]; l1 += red[2 * nw + q]; c += red[3 * nw + q]; }
+        const double LapLogPsi = 0.5 * l1 + l;                // :189 then pair terms
+        double Kin = 2.0 * LapLogPsi;                         // :305
+        Kin = Kin + c;
+        Kin = -0.5 * Kin;                                     // :315
+        out[(size_t)slot * 3 + 0] = Kin + a;                  // :316
+        out[(size_t)slot * 3 + 1] = Kin;
+        out[(size_t)slot * 3 + 2] = a;
+    }
+}
+
+// =====================================================================================
+// K5 and layout kernels
+// =====================================================================================
+__global__ void k_commit_beads(DevParams P, double *__restrict__ paths, int64_t n,
+                               const int32_t *__restrict__ walker, const int32_t *__restrict__ ipv,
+                               const int32_t *__restrict__ ibv, const double *__restrict__ x)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * P.dim) return;
+    const int64_t i = t / P.dim;
+    const int k = (int)(t - i * P.dim);
+    const size_t sl = slice_doubles(P.dim, P.NpPad);
+    paths[((size_t)walker[i] * P.M + ibv[i]) * sl + (size_t)k * P.NpPad + (ipv[i] - 1)] = x[t];
+}
+
+// Swap accept branch (vpi_mod.f90:2454-2464): exchange beads Nb..2Nb of particles iw, ik.
+__global__ void k_swap_tails(DevParams P, double *__restrict__ paths, int walker, int iw, int ik)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = P.Nb + 1;
+    if (t >= nb * P.dim) return;
+    const int ib = P.Nb + t / P.dim, k = t % P.dim;
+    const size_t sl = slice_doubles(P.dim, P.NpPad);
+    double *row = paths + ((size_t)walker * P.M + ib) * sl + (size_t)k * P.NpPad;
+    const double a = row[iw - 1], c = row[ik - 1];
+    row[iw - 1] = c;
+    row[ik - 1] = a;
+}
+
+// raw: reference layout Path(dim,Np,0:2Nb) for walkers [w0, w0+nw); one thread per element.
+__global__ void k_pack(DevParams P, double *__restrict__ paths, const double *__restrict__ raw,
+                       int w0, int nw)
+{
+    const size_t per = (size_t)P.dim * P.Np * P.M;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per * nw) return;
+    const int wl = (int)(t / per);
+    size_t r = t - (size_t)wl * per;
+    const int ib = (int)(r / ((size_t)P.dim * P.Np));
+    r -= (size_t)ib * P.dim * P.Np;
+    const int jp = (int)(r / P.dim), k = (int)(r % P.dim);
+    const size_t sl = slice_doubles(P.dim, P.NpPad);
+    paths[((size_t)(w0 + wl) * P.M + ib) * sl + (size_t)k * P.NpPad + jp] = raw[t];
+}
+
+__global__ void k_unpack(DevParams P, const double *__restrict__ paths, double *__restrict__ raw,
+                         int w0, int nw)
+{
+    const size_t per = (size_t)P.dim * P.Np * P.M;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per * nw) return;
+    const int wl = (int)(t / per);
+    size_t r = t - (size_t)wl * per;
+    const int ib = (int)(r / ((size_t)P.dim * P.Np));
+    r -= (size_t)ib * P.dim * P.Np;
+    const int jp = (int)(r / P.dim), k = (int)(r % P.dim);
+    const size_t sl = slice_doubles(P.dim, P.NpPad);
+    raw[t] = paths[((size_t)(w0 + wl) * P.M + ib) * sl + (size_t)k * P.NpPad + jp];
+}
+
+// =====================================================================================
+// launchers (host)
+// =====================================================================================
+#define PIGS_DISPATCH(P, CALL)                                              \
+    do {                                                                    \
+        if ((P).trap) {                                                     \
+            if ((P).dim == 1) { CALL(1, true); }                            \
+            else if ((P).dim == 2) { CALL(2, true); }                       \
+            else { CALL(3, true); }                                         \
+        } else {                                                            \
+            if ((P).dim == 1) { CALL(1, false); }                           \
+            else if ((P).dim == 2) { CALL(2, false); }                      \
+            else { CALL(3, false); }                                        \
+        }                                                                   \
+    } while (0)
+
+static int k1_grid(int n_items)
+{
+    const int per_block = 4;                         // waves (items in flight) per workgroup
+    int blocks = (n_items + per_block - 1) / per_block;
+    const int cap = 256 * 8;                         // 256 CUs x 8 workgroups of 256 threads
+    return blocks < cap ? (blocks > 0 ? blocks : 1) : cap;
+}
+
+hipError_t launch_delta_action(const DevParams &P, const double *paths, const double *VT,
+                               const double *WF, int n_items, const int32_t *walker,
+                               const int32_t *ip, const int32_t *ib, const double *xnew,
+                               const double *xold, double *out, double *parts, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+#define CALL(D, T)                                                                         \
+    hipLaunchKernelGGL((k_delta_action<D, T>), dim3(k1_grid(n_items)), dim3(256), 0, st, P, \
+                       paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+    PIGS_DISPATCH(P, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+static int slice_block(const DevParams &P)
+{
+    int t = ((P.Np + 63) / 64) * 64;
+    return t > 256 ? 256 : t;
+}
+
+hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT,
+                               int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
+                               int force_mode, int want_spring, double *out, hipStream_t st)
+{
+    if (n_slots <= 0) return hipSuccess;
+    const int bs = slice_block(P);
+    const size_t lds = ((size_t)P.dim * P.NpPad + 3 * (bs / 64)) * sizeof(double);
+#define CALL(D, T)                                                                       \
+    hipLaunchKernelGGL((k_slice_energy<D, T>), dim3(n_slots), dim3(bs), lds, st, P, paths, \
+                       VT, n_slots, slot_walker, slot_ib, force_mode, want_spring, out)
+    PIGS_DISPATCH(P, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_therm_combine(const DevParams &P, int n, const double *slices, double *E,
+                                double *Ec, double *Ep, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_therm_combine, dim3((n + 63) / 64), dim3(64), 0, st, P, n, slices, E, Ec, Ep);
+    return hipGetLastError();
+}
+
+hipError_t launch_local_energy(const DevParams &P, const double *paths, const double *VT,
+                               const double *WF, int n_slots, const int32_t *slot_walker, int ib,
+                               double *out, hipStream_t st)
+{
+    if (n_slots <= 0) return hipSuccess;
+    const int bs = slice_block(P);
+    const size_t lds = ((size_t)P.dim * P.NpPad + 4 * (bs / 64)) * sizeof(double);
+#define CALL(D, T)                                                                       \
+    hipLaunchKernelGGL((k_local_energy<D, T>), dim3(n_slots), dim3(bs), lds, st, P, paths, \
+                       VT, WF, n_slots, slot_walker, ib, out)
+    PIGS_DISPATCH(P, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_commit_beads(const DevParams &P, double *paths, int64_t n, const int32_t *walker,
+                               const int32_t *ip, const int32_t *ib, const double *x, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int64_t tot = n * P.dim;
+    hipLaunchKernelGGL(k_commit_beads, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P,
+                       paths, n, walker, ip, ib, x);
+    return hipGetLastError();
+}
+
+hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int iw, int ik, hipStream_t st)
+{
+    const int tot = (P.Nb + 1) * P.dim;
+    hipLaunchKernelGGL(k_swap_tails, dim3((tot + 255) / 256), dim3(256), 0, st, P, paths, walker, iw, ik);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const DevParams &P, double *paths, const double *raw, int w0, int nw, hipStream_t st)
+{
+    const size_t tot = (size_t)P.dim * P.Np * P.M * nw;
+    if (!tot) return hipSuccess;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, paths, raw, w0, nw);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const DevParams &P, const double *paths, double *raw, int w0, int nw, hipStream_t st)
+{
+    const size_t tot = (size_t)P.dim * P.Np * P.M * nw;
+    if (!tot) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, paths, raw, w0, nw);
+    return hipGetLastError();
+}
+
+} // namespace pigs

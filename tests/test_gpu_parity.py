@@ -1,0 +1,297 @@
+"""Parity of the HIP path (through the C ABI, libpigs_hip.so) with the reference.
+
+Checkers, in order of authority: the committed golden vectors (generated from the unmodified
+reference), the pinned C restatement (oracle/) on fresh seeded inputs, the reference build
+itself where oracle/_ref travelled to this machine, and size-independent properties at the full
+BASELINE sizes.
+
+Tolerances (fp64 path; stated per SURVEY §7 hard-part 2 and BASELINE.json's 1e-10):
+  * per-pair terms are bit-identical to the reference's, only the summation order differs, so
+    |DeltaS_gpu - DeltaS_ref| <= 2e-13 * (sum of |terms|)       (helpers.delta_s_tolerance)
+  * accept/reject decisions on a fixed uniform are identical
+  * energy estimators (ThermEnergy, LocalEnergy, PotentialEnergy) agree to 1e-10 relative
+  * index / layout work (upload, download, commit, swap) is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import config_from_golden, load_golden, system_from_golden
+from helpers import delta_s_tolerance, same_bits, term_scales
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-10
+
+
+def _tables(d):
+    if "VTable" in d:
+        return d["VTable"], d["LogWF"]
+    t = load_golden("tables_he4_n64")
+    return t["VTable"], t["LogWF"]
+
+
+def _close_rel(a, b, rel=REL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return bool(np.all(np.abs(a - b) <= rel * np.abs(b) + 1e-300))
+
+
+@pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "ho1d_n2", "trap3d_n8", "pbc2d_n16"])
+def test_delta_action_vs_golden(gpu_lib, name):
+    d = load_golden(name)
+    cfg, S = config_from_golden(d), system_from_golden(d)
+    VT, WF = _tables(d)
+    n = len(d["ip"])
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=2) as ctx:
+        ctx.upload(1, d["Path"])
+        assert same_bits(ctx.download(1), d["Path"])
+        w = np.ones(n, np.int32)
+        dS = ctx.delta_action_batch(w, d["ip"], d["ib"], d["xnew"], d["xold"])
+        parts = ctx.delta_action_parts(w, d["ip"], d["ib"], d["xnew"], d["xold"])
+    ref = d["DeltaS"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(dS), np.isnan(ref))            # NaN (r<dr, quirk Q4) parity
+    sv, sf, su = term_scales(S, VT, WF, d["Path"], d["ip"], d["ib"], d["xnew"], d["xold"])
+    tol = delta_s_tolerance(S, sv, sf, su)
+    err = np.abs(dS - ref)[fin]
+    assert np.all(err <= tol[fin]), (err.max(), (err / tol[fin]).max())
+    # components: DeltaPot, DeltaF2, DeltaLogPsi
+    pr = d["parts"]
+    assert np.all(np.abs(parts[fin, 0] - pr[fin, 0]) <= 2e-13 * sv[fin] + 1e-300)
+    assert np.all(np.abs(parts[fin, 1] - pr[fin, 1]) <= 8e-13 * sf[fin] ** 2 + 1e-300)
+    assert np.all(np.abs(parts[fin, 2] - pr[fin, 2]) <= 2e-13 * su[fin] + 1e-300)
+    # Metropolis decisions on a fixed uniform stream are identical
+    u = np.random.default_rng(1).uniform(size=n)
+    with np.errstate(over="ignore", invalid="ignore"):
+        assert np.array_equal(np.exp(-dS) >= u, np.exp(-ref) >= u)
+
+
+@pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "ho1d_n2", "trap3d_n8", "pbc2d_n16"])
+def test_energies_vs_golden(gpu_lib, name):
+    d = load_golden(name)
+    cfg = config_from_golden(d)
+    VT, WF = _tables(d)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=3) as ctx:
+        for w in range(3):
+            ctx.upload(w, d["Path"])
+        pot_f2 = np.array([ctx.PotentialEnergy(2, ib, True) for ib in range(cfg.M)])
+        pot0 = np.array([ctx.PotentialEnergy(0, ib, False)[0] for ib in range(cfg.M)])
+        E, Ec, Ep = ctx.therm_energy_batch()
+        le0 = ctx.local_energy_batch(0)
+        le1 = ctx.local_energy_batch(2 * cfg.Nb, walkers=[1])
+    fin = np.isfinite(d["pot_f2"]).all(1)
+    assert _close_rel(pot_f2[fin], d["pot_f2"][fin]) and _close_rel(pot0[fin], d["pot_only"][fin])
+    if np.all(np.isfinite(d["therm"])):
+        for w in range(3):
+            assert _close_rel([E[w], Ec[w], Ep[w]], d["therm"])
+    if np.all(np.isfinite(d["local"])):
+        assert _close_rel([le0[0][2], le0[1][2], le0[2][2]], d["local"][0])
+        assert _close_rel([le1[0][0], le1[1][0], le1[2][0]], d["local"][1])
+
+
+@pytest.mark.parametrize("tag", ["lj", "dipolar"])
+def test_external_tables_vs_golden(gpu_lib, tag):
+    """Config-2 (Lennard-Jones) and config-5 (dipolar) potentials, pinned at the table boundary."""
+    base, d = load_golden("he4_n64_eq"), load_golden(f"he4_n64_table_{tag}")
+    cfg, S = config_from_golden(base), system_from_golden(base)
+    WF = load_golden("tables_he4_n64")["LogWF"]
+    VT = d["VTable"]
+    n = len(d["ip"])
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
+        ctx.upload(0, base["Path"])
+        dS = ctx.delta_action_batch(np.zeros(n, np.int32), d["ip"], d["ib"], d["xnew"], d["xold"])
+        E, Ec, Ep = ctx.therm_energy_batch()
+    sv, sf, su = term_scales(S, VT, WF, base["Path"], d["ip"], d["ib"], d["xnew"], d["xold"])
+    assert np.all(np.abs(dS - d["DeltaS"]) <= delta_s_tolerance(S, sv, sf, su))
+    assert _close_rel([E[0], Ec[0], Ep[0]], d["therm"])
+
+
+def _random_batch(rng, S, Paths, n, sigma):
+    W = Paths.shape[0]
+    w = rng.integers(0, W, n).astype(np.int32)
+    ip = rng.integers(1, S.Np + 1, n).astype(np.int32)
+    ib = rng.integers(0, S.M, n).astype(np.int32)
+    ib[::9] = 0
+    ib[4::9] = 2 * S.Nb
+    xold = Paths[w, ib, ip - 1].copy()
+    xnew = xold + rng.normal(0, sigma, xold.shape)
+    L = np.asarray(S.Lbox[:S.dim])
+    xnew = np.where(xnew > L / 2, xnew - L, xnew)
+    xnew = np.where(xnew < -L / 2, xnew + L, xnew)
+    return w, ip, ib, xnew, xold
+
+
+def _worldlines(oracle, S, W, seed0, spread):
+    """W seeded worldlines: reference-style init (all beads equal) + a Brownian-bridge-like spread."""
+    rng = np.random.default_rng(seed0)
+    Ps = []
+    L = np.asarray(S.Lbox[:S.dim])
+    for w in range(W):
+        P, _ = oracle.init_path(S, 1982 + w)
+        P = P + rng.normal(0, spread, P.shape)
+        P = np.where(P > L / 2, P - L, P)
+        P = np.where(P < -L / 2, P + L, P)
+        Ps.append(P)
+    return np.stack(Ps)
+
+
+@pytest.mark.parametrize("Np,Nb,W,n", [(64, 40, 3, 4000), (256, 80, 4, 6000), (37, 5, 2, 1500)])
+def test_delta_action_vs_oracle_seeded(gpu_lib, oracle, Np, Nb, W, n):
+    """Fresh seeded batches over several walkers at the C2 / C3 shapes (+ a ragged Np)."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(dim=3, Np=Np, Nb=Nb)
+    cfg = SystemConfig(dim=3, Np=Np, Nb=Nb)
+    VT, WF = oracle.tables(S)                       # == the reference's tables bit for bit
+    Paths = _worldlines(oracle, S, W, 77, 0.12)
+    rng = np.random.default_rng(Np)
+    w, ip, ib, xnew, xold = _random_batch(rng, S, Paths, n, 0.1)
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w, ip, ib, xnew, xold)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        assert same_bits(ctx.download_all(), Paths)
+        got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+        E, Ec, Ep = ctx.therm_energy_batch()
+        le = ctx.local_energy_batch(0)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    sv = np.zeros(n); sf = np.zeros(n); su = np.zeros(n)
+    for k in range(W):
+        m = w == k
+        sv[m], sf[m], su[m] = term_scales(S, VT, WF, Paths[k], ip[m], ib[m], xnew[m], xold[m])
+    tol = delta_s_tolerance(S, sv, sf, su)
+    assert np.all(np.abs(got - want)[fin] <= tol[fin])
+    u = rng.uniform(size=n)
+    with np.errstate(over="ignore", invalid="ignore"):
+        assert np.array_equal(np.exp(-got) >= u, np.exp(-want) >= u)
+    for k in range(W):
+        te = oracle.therm_energy(S, VT, Paths[k])
+        if np.all(np.isfinite(te)):
+            assert _close_rel([E[k], Ec[k], Ep[k]], te)
+        lo = oracle.local_energy(S, WF, VT, Paths[k][0])
+        if np.all(np.isfinite(lo)):
+            assert _close_rel([le[0][k], le[1][k], le[2][k]], lo)
+
+
+def test_against_reference_build_if_present(gpu_lib):
+    """Where oracle/_ref travelled to this machine, compare with the reference ITSELF."""
+    from oracle.pyoracle import Ref, System
+    from pathintegralgroundstate_amd import SystemConfig
+    if not Ref.available():
+        pytest.skip("oracle/_ref not present on this machine")
+    ref = Ref()
+    S = System(dim=3, Np=64, Nb=40)
+    cfg = SystemConfig(dim=3, Np=64, Nb=40)
+    VT, WF = ref.tables(S)
+    P, _ = ref.init(1982)
+    for ip in range(1, S.Np + 1):                     # a few reference moves so beads spread out
+        ref.translate_chain(0.3, WF, VT, ip, P)
+        ref.diag_move("Bisection", WF, VT, 4, ip, P)
+        ref.diag_move("MoveHeadBisection", WF, VT, 3, ip, P)
+        ref.diag_move("MoveTailBisection", WF, VT, 3, ip, P)
+    rng = np.random.default_rng(9)
+    w, ip, ib, xnew, xold = _random_batch(rng, S, P[None], 1500, 0.1)
+    want = np.array([ref.update_action(WF, VT, P, int(ip[i]), int(ib[i]), xnew[i], xold[i])
+                     for i in range(len(ip))])
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
+        ctx.upload(0, P)
+        got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+        te = ctx.ThermEnergy(0)
+        le = ctx.LocalEnergy(0, 2 * S.Nb)
+    sv, sf, su = term_scales(S, VT, WF, P, ip, ib, xnew, xold)
+    assert np.all(np.abs(got - want) <= delta_s_tolerance(S, sv, sf, su))
+    assert _close_rel(te, ref.therm_energy(VT, P))
+    assert _close_rel(le, ref.local_energy(WF, VT, P[2 * S.Nb]))
+
+
+def test_commit_swap_and_edge_cases(gpu_lib, oracle):
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(dim=3, Np=64, Nb=6)
+    cfg = SystemConfig(dim=3, Np=64, Nb=6)
+    VT, WF = oracle.tables(S)
+    Paths = _worldlines(oracle, S, 2, 5, 0.1)
+    rng = np.random.default_rng(2)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=2) as ctx:
+        ctx.upload_all(Paths)
+        # empty batch is a no-op
+        assert ctx.delta_action_batch([], [], [], np.zeros((0, 3)), np.zeros((0, 3))).size == 0
+        # commit: bit-exact scatter, last write wins in host order for distinct targets
+        w, ip, ib, xnew, xold = _random_batch(rng, S, Paths, 200, 0.2)
+        key = (w.astype(np.int64) * 1000 + ip) * 1000 + ib
+        _, first = np.unique(key, return_index=True)
+        w, ip, ib, xnew = w[first], ip[first], ib[first], xnew[first]
+        ctx.commit_beads(w, ip, ib, xnew)
+        Paths[w, ib, ip - 1] = xnew
+        assert same_bits(ctx.download_all(), Paths)
+        # swap tails: beads Nb..2Nb of two particles exchange (reference Swap accept branch)
+        ctx.swap_tails(1, 3, 17)
+        t = Paths[1, S.Nb:, 2].copy()
+        Paths[1, S.Nb:, 2] = Paths[1, S.Nb:, 16]
+        Paths[1, S.Nb:, 16] = t
+        assert same_bits(ctx.download_all(), Paths)
+        # bad indices are refused, not faulted on
+        with pytest.raises(gpu_lib.PigsError):
+            ctx.delta_action_batch([0], [65], [0], np.zeros((1, 3)), np.zeros((1, 3)))
+        with pytest.raises(gpu_lib.PigsError):
+            ctx.delta_action_batch([2], [1], [0], np.zeros((1, 3)), np.zeros((1, 3)))
+        with pytest.raises(gpu_lib.PigsError):
+            ctx.commit_beads([0], [1], [13], np.zeros((1, 3)))
+        # row ip of the slice is never read (aliasing contract): garbage there changes nothing
+        w1, ip1, ib1, xn1, xo1 = _random_batch(rng, S, Paths, 64, 0.1)
+        a = ctx.delta_action_batch(w1, ip1, ib1, xn1, xo1)
+        ctx.commit_beads(w1, ip1, ib1, np.full((64, 3), 1e300))
+        b = ctx.delta_action_batch(w1, ip1, ib1, xn1, xo1)
+        assert same_bits(a, b)
+
+
+def test_full_size_properties(gpu_lib, oracle):
+    """BASELINE config 3 (N=256, 161 beads, 128 walkers): properties that need no oracle run."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(dim=3, Np=256, Nb=80)
+    cfg = SystemConfig(dim=3, Np=256, Nb=80)
+    t = load_golden("tables_he4_n256")
+    VT, WF = t["VTable"], t["LogWF"]
+    W = 128
+    rng = np.random.default_rng(123)
+    L = S.Lbox[0]
+    # jittered-lattice worldlines (no overlaps -> finite potentials), cheap to build at this size
+    g = int(np.ceil(S.Np ** (1 / 3)))
+    lat = (np.stack(np.meshgrid(*[np.arange(g)] * 3, indexing="ij"), -1).reshape(-1, 3)[:S.Np] + 0.5) * (L / g) - L / 2
+    Paths = lat[None, None] + rng.normal(0, 0.08, (W, S.M, S.Np, 3))
+    Paths = np.where(Paths > L / 2, Paths - L, Paths)
+    Paths = np.where(Paths < -L / 2, Paths + L, Paths)
+    n = W * S.M                                       # one full-chain stage: every slice once
+    w = np.repeat(np.arange(W, dtype=np.int32), S.M)
+    ib = np.tile(np.arange(S.M, dtype=np.int32), W)
+    ip = np.repeat(rng.integers(1, S.Np + 1, W).astype(np.int32), S.M)
+    xa = Paths[w, ib, ip - 1].copy()
+    xb = xa + rng.normal(0, 0.05, xa.shape)
+    xc = xa + rng.normal(0, 0.05, xa.shape)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        zero = ctx.delta_action_batch(w, ip, ib, xa, xa)
+        ab = ctx.delta_action_batch(w, ip, ib, xb, xa)
+        ba = ctx.delta_action_batch(w, ip, ib, xa, xb)
+        bc = ctx.delta_action_batch(w, ip, ib, xc, xb)
+        ac = ctx.delta_action_batch(w, ip, ib, xc, xa)
+        perm = rng.permutation(n)
+        ab_p = ctx.delta_action_batch(w[perm], ip[perm], ib[perm], xb[perm], xa[perm])
+        # K1 vs K2+K5: DeltaPot of a move == PotentialEnergy(after commit) - PotentialEnergy(before)
+        sel = rng.choice(n, 24, replace=False)
+        parts = ctx.delta_action_parts(w[sel], ip[sel], ib[sel], xb[sel], xa[sel])
+        before = np.array([ctx.PotentialEnergy(int(w[i]), int(ib[i]))[0] for i in sel])
+        ctx.commit_beads(w[sel], ip[sel], ib[sel], xb[sel])
+        after = np.array([ctx.PotentialEnergy(int(w[i]), int(ib[i]))[0] for i in sel])
+        E, Ec, Ep = ctx.therm_energy_batch()
+    assert np.all(zero == 0.0)                        # x -> x is exactly zero
+    assert same_bits(ab, -ba)                         # exact antisymmetry
+    assert same_bits(ab_p, ab[perm])                  # batch order does not matter (determinism)
+    assert np.all(np.abs(ab + bc - ac) <= 1e-9 * (np.abs(ab) + np.abs(bc) + np.abs(ac)) + 1e-10)
+    assert np.all(np.abs((after - before) - parts[:, 0]) <= 1e-10 * np.abs(before))
+    assert np.all(np.isfinite(E)) and np.all(np.abs(Ec + Ep - E) <= 1e-9 * np.abs(E))
+    # spot-check a sample of the full-size batch against the pinned oracle
+    sel = rng.choice(n, 600, replace=False)
+    Paths_before = Paths
+    want = oracle.delta_action_batch(S, WF, VT, Paths_before, w[sel], ip[sel], ib[sel], xb[sel], xa[sel])
+    assert np.all(np.abs(ab[sel] - want) <= 1e-10 * np.abs(want) + 1e-11)

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: namelist front end, derived box / cutoff / grid values,
+host table fill, and that the C-ABI library loads and exports every declared symbol."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from helpers import same_bits, ulp_diff
+from pathintegralgroundstate_amd import SystemConfig, read_namelists
+
+STOCK = """&system
+ dim      = 3,          ! Dimensions
+ Np       = 64,         ! Number of particles
+ density  = 0.365d0,    ! Density
+ trap     = F           ! T if the system is trapped, F otherwise
+/
+&samp
+ resume   = F
+ dt       = 5.00d-3,
+ Nb       = 32,
+ seed     = 1982,
+ delta_cm = 0.12d0,
+ CMFreq   = 1,
+ sampling = 'bis',\t! Movement type
+ Lstag    = 32,
+ Nlev     = 4,
+ Nstag    = 5,
+ Nblock   = 400,
+ Nstep    = 100,
+ Nbin     = 100,
+ Nk       = 50
+/
+&obdm
+ swapping = T, CWorm = 0.5d0, Nobdm = 10, Npw = 0
+/
+&wavefun
+ Nmax     = 10000, wf_table = T, v_table  = T
+/
+&jastrow
+ Rm       = 1.20d0
+/
+"""
+
+
+def test_namelists_stock_input():
+    g = read_namelists(STOCK)
+    assert g["system"] == {"crystal": False, "trap": False, "dim": 3, "np": 64, "density": 0.365}
+    assert g["samp"]["sampling"] == "bis" and g["samp"]["nlev"] == 4 and g["samp"]["dt"] == 5e-3
+    assert g["obdm"] == {"swapping": True, "cworm": 0.5, "nobdm": 10, "npw": 0}
+    assert g["wavefun"] == {"nmax": 10000, "wf_table": True, "v_table": True}
+    c = SystemConfig.from_namelists(STOCK)
+    assert (c.dim, c.Np, c.Nb, c.M, c.Nmax) == (3, 64, 32, 65, 10000)
+    assert c.path_shape == (65, 64, 3)
+
+
+def test_namelist_defaults_and_trap():
+    txt = "&system\n dim=1, Np=2, trap=T\n/\n&samp\n dt=1.d-2, Nb=10\n/\n&extpot\n a_ho = 1.5d0\n/\n&jastrow\n Rm=0.5\n/\n"
+    c = SystemConfig.from_namelists(txt)
+    assert c.trap and c.a_ho[0] == 1.5 and c.seed == 1982 and c.Lstag == 2 and c.Nlev == 1
+    assert not c.swapping and c.CWorm == 0.0 and c.Nmax == 10000
+    # vpi.f90:84-92: rcut = 10*(3*a)^(1/dim)
+    assert c.rcut == 10.0 * (3.0 * 1.5)
+
+
+@pytest.mark.parametrize("name", ["tables_he4_n64", "tables_he4_n256", "pbc2d_n16"])
+def test_derived_quantities_match_reference(name):
+    """Lbox, rcut, dr as the reference derives them (vpi.f90:112-128, vpi_mod.f90:94), bitwise."""
+    d = load_golden(name)
+    c = SystemConfig(dim=int(d["dim"]), Np=int(d["Np"]), Nb=int(d["Nb"]), density=float(d["density"]))
+    assert c.Lbox[0] == d["Lbox"][0] and c.rcut == float(d["rcut"]) and c.dr == float(d["dr"])
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "pigs_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pigs_[a-z_]+)\s*\(", txt)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from pathintegralgroundstate_amd import api
+    from pathintegralgroundstate_amd.build import build
+    build()
+    L = api.load_library()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    assert sorted(api.ABI_SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(L, s), f"libpigs_hip.so does not export {s}"
+    assert L.pigs_abi_version() == 1
+
+
+def test_host_table_fill_matches_reference_tables():
+    from pathintegralgroundstate_amd import api
+    from pathintegralgroundstate_amd.build import build
+    build()
+    for name in ("tables_he4_n64", "tables_he4_n256"):
+        t = load_golden(name)
+        c = SystemConfig(dim=3, Np=int(t["Np"]), Nb=int(t["Nb"]))
+        VT, WF = api.build_tables(c)
+        # table construction gets the looser bar of SURVEY §8c (<= 4 ulp); kernels are always
+        # fed the reference's own tables in the parity tests
+        assert np.nanmax(ulp_diff(VT, t["VTable"])) <= 4 and np.nanmax(ulp_diff(WF, t["LogWF"])) <= 4
+        assert np.isnan(VT[1]) and WF[1] == -np.inf and VT[0] == VT[2]
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the product must raise -- never fall back to a CPU path."""
+    from pathintegralgroundstate_amd import api
+    from pathintegralgroundstate_amd.build import build
+    build()
+    if api.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    t = load_golden("tables_he4_n64")
+    c = SystemConfig(dim=3, Np=64, Nb=40)
+    with pytest.raises(api.PigsError, match="no HIP device|status -3|status -2"):
+        api.PigsContext(c, t["VTable"], t["LogWF"], n_walkers=1)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from pathintegralgroundstate_amd import api
+    saved = api._lib
+    api._lib = None
+    try:
+        with pytest.raises(api.PigsError, match="no CPU fallback"):
+            api.load_library(str(tmp_path / "libpigs_hip.so"))
+    finally:
+        api._lib = saved
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "pathintegralgroundstate_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".f90")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert "pyoracle" not in src and "pigs_oracle" not in src and "libvpiref" not in src, f

@@ -1,0 +1,110 @@
+"""The C restatement (oracle/pigs_oracle.c) against the committed golden vectors that
+tests/golden/make_golden.py generated from the unmodified reference: bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, system_from_golden
+from helpers import same_bits
+
+CASES = ["he4_n64_eq", "he4_n64_rnd", "ho1d_n2", "trap3d_n8", "pbc2d_n16"]
+
+
+def _tables(name, d):
+    if "VTable" in d:
+        return d["VTable"], d["LogWF"]
+    t = load_golden("tables_he4_n64")
+    return t["VTable"], t["LogWF"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_update_action_bit_exact(oracle, name):
+    d = load_golden(name)
+    S = system_from_golden(d)
+    VT, WF = _tables(name, d)
+    n = len(d["ip"])
+    got = np.array([oracle.update_action(S, WF, VT, d["Path"], int(d["ip"][i]), int(d["ib"][i]),
+                                         d["xnew"][i], d["xold"][i]) for i in range(n)])
+    assert same_bits(got, d["DeltaS"])
+    # batched form == per-call form
+    W = np.zeros(n, np.int32)
+    got_b = oracle.delta_action_batch(S, WF, VT, d["Path"][None], W, d["ip"], d["ib"], d["xnew"], d["xold"])
+    assert same_bits(got_b, d["DeltaS"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_update_pot_wf_parts_bit_exact(oracle, name):
+    d = load_golden(name)
+    S = system_from_golden(d)
+    VT, WF = _tables(name, d)
+    for i in range(0, len(d["ip"]), 3):
+        ip, ib = int(d["ip"][i]), int(d["ib"][i])
+        odd = ib % 2 == 1
+        dp, df = oracle.update_pot(S, VT, ip, d["Path"][ib], d["xnew"][i], d["xold"][i], odd)
+        assert same_bits([dp, df], d["parts"][i, :2])
+        if ib in (0, 2 * S.Nb):
+            dw = oracle.update_wf(S, WF, ip, d["Path"][ib], d["xnew"][i], d["xold"][i])
+            assert same_bits([dw], d["parts"][i, 2:])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_energies_bit_exact(oracle, name):
+    d = load_golden(name)
+    S = system_from_golden(d)
+    VT, WF = _tables(name, d)
+    P = d["Path"]
+    pe = np.array([oracle.potential_energy(S, VT, P[ib], True) for ib in range(S.M)])
+    pe0 = np.array([oracle.potential_energy(S, VT, P[ib], False)[0] for ib in range(S.M)])
+    assert same_bits(pe, d["pot_f2"]) and same_bits(pe0, d["pot_only"])
+    le = np.array([oracle.local_energy(S, WF, VT, P[0]), oracle.local_energy(S, WF, VT, P[2 * S.Nb])])
+    assert same_bits(le, d["local"])
+    assert same_bits(np.array(oracle.therm_energy(S, VT, P)), d["therm"])
+
+
+@pytest.mark.parametrize("tag", ["lj", "dipolar"])
+def test_external_table_boundary(oracle, tag):
+    """LJ / dipolar potentials are not active code in the reference: parity is
+    pinned at the table boundary -- same externally filled VTable through both."""
+    base = load_golden("he4_n64_eq")
+    d = load_golden(f"he4_n64_table_{tag}")
+    S = system_from_golden(base)
+    WF = load_golden("tables_he4_n64")["LogWF"]
+    VT, P = d["VTable"], base["Path"]
+    got = np.array([oracle.update_action(S, WF, VT, P, int(d["ip"][i]), int(d["ib"][i]),
+                                         d["xnew"][i], d["xold"][i]) for i in range(len(d["ip"]))])
+    assert same_bits(got, d["DeltaS"])
+    assert same_bits(np.array(oracle.therm_energy(S, VT, P)), d["therm"])
+    assert same_bits(np.array([oracle.potential_energy(S, VT, P[ib], True) for ib in range(S.M)]), d["pot_f2"])
+
+
+def test_tables_bit_exact(oracle):
+    for name in ("tables_he4_n64", "tables_he4_n256"):
+        t = load_golden(name)
+        S = system_from_golden(t)
+        VT, WF = oracle.tables(S)
+        assert same_bits(VT, t["VTable"]) and same_bits(WF, t["LogWF"])
+        # quirk Q4: entry 1 is V(0)=NaN / u(0)=-inf, ghost cells mirror entries 2 and Nmax
+        assert np.isnan(VT[1]) and WF[1] == -np.inf
+        assert VT[0] == VT[2] and VT[S.Nmax + 1] == VT[S.Nmax]
+
+
+def test_primitives_bit_exact(oracle):
+    p = load_golden("primitives_n64")
+    t = load_golden("tables_he4_n64")
+    S = system_from_golden(t)
+    for o in (0, 1, 2):
+        got = np.array([oracle.interpolate(o, S.Nmax, S.dr, t["VTable"], x) for x in p["x"]])
+        assert same_bits(got, p[f"interp{o}"])
+    gf = np.array([[oracle.green_function(o, ib, S.Nb, 5e-3, 1.2345678901234, -9.87654321)
+                    for ib in (0, 1, 2, 39, 40, 79, 80)] for o in (0, 1)])
+    assert same_bits(gf, p["green"])
+
+
+def test_rng_bit_exact(oracle):
+    r = load_golden("rng_seed1982")
+    g = oracle.rng(1982)
+    u = np.array([oracle.grnd(g) for _ in range(len(r["grnd"]))])
+    assert same_bits(u, r["grnd"])
+    assert g.mti == int(r["mti_after"]) and np.array_equal(np.array(g.mt[:], np.uint32), r["mt_after"])
+    gs = np.array([oracle.rangauss(g, 1.0, 0.0) for _ in range(len(r["rangauss"]))])
+    assert same_bits(gs, r["rangauss"])
+    assert g.mti == int(r["mti_after_gauss"]) and np.array_equal(np.array(g.mt[:], np.uint32), r["mt_after_gauss"])
