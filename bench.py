@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement of BASELINE.json on MI355X.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): liquid 4He, N=256
+particles, 161 beads (reference namelist Nb=80), 128 independent walkers resident per GPU.
+One STEP = one pass of the hot path (K1, the batched Delta-S evaluator that replaces the
+reference's `call UpdateAction`, reference vpi_mod.f90:2491-2841) over one full-chain stage:
+for every walker one particle is displaced and the Delta S of each of its 161 beads is
+evaluated, i.e. 128*161 = 20 608 items, each visiting its 255 partners -- every resident slice
+is read exactly once per step, exactly the access pattern of one lock-step TranslateChain stage
+of the sampler.  Proposals (synthetic, seeded) are resident in HBM before the timed region.
+
+metric  : bead-pair action evals / s (one eval = one (proposal bead, partner) visit = both the
+          old and the new distance + their table lookups)
+roofline: HBM bound named by the north star; achieved = ALGORITHMIC bytes per launch
+          (6 200 B per item at N=256) / average launch duration from HIP events on the
+          context's own stream.
+cpu_baseline: the pinned scalar C restatement of the same routine (oracle/, kind "port"),
+          timed on this machine's host cores on a bounded sample of the same batch.
+
+N>1 (launched by torch.distributed.run): one process per GPU, walkers shard across ranks (weak
+scaling: 128 walkers per GPU), no data-path collective; one all-reduce of the block-estimator
+vector (RCCL) closes the timed region, as the sampler does once per block.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_workload(cfg, W, nsets, seed):
+    """Seeded synthetic worldlines + `nsets` full-chain proposal stages."""
+    rng = np.random.default_rng(seed)
+    L = cfg.Lbox[0]
+    g = int(np.ceil(cfg.Np ** (1.0 / 3.0)))
+    lat = (np.stack(np.meshgrid(*[np.arange(g)] * 3, indexing="ij"), -1).reshape(-1, 3)[:cfg.Np]
+           + 0.5) * (L / g) - L / 2
+    # bead spread ~ sqrt(dt*|ib-Nb|)-like noise around a jittered lattice (no hard overlaps)
+    ibs = np.arange(cfg.M)
+    sig = 0.03 + np.sqrt(cfg.dt * np.minimum(np.abs(ibs - cfg.Nb), 16))[None, :, None, None]
+    Paths = lat[None, None] + rng.normal(0, 0.05, (W, 1, cfg.Np, 3)) + sig * rng.normal(0, 0.5, (W, cfg.M, cfg.Np, 3))
+    Paths = np.where(Paths > L / 2, Paths - L, Paths)
+    Paths = np.where(Paths < -L / 2, Paths + L, Paths)
+    sets = []
+    w = np.repeat(np.arange(W, dtype=np.int32), cfg.M)
+    ib = np.tile(np.arange(cfg.M, dtype=np.int32), W)
+    for _ in range(nsets):
+        ip = np.repeat(rng.integers(1, cfg.Np + 1, W).astype(np.int32), cfg.M)
+        xold = Paths[w, ib, ip - 1].copy()
+        xnew = xold + rng.normal(0, np.sqrt(cfg.dt), xold.shape)
+        xnew = np.where(xnew > L / 2, xnew - L, xnew)
+        xnew = np.where(xnew < -L / 2, xnew + L, xnew)
+        sets.append((w, ip, ib, xnew, xold))
+    return Paths, sets
+
+
+def cpu_baseline(cfg, VT, WF, Paths, sets, budget_s=12.0):
+    """Time the pinned C restatement (oracle/) on this host: 1 core, bounded sample."""
+    from oracle.pyoracle import Oracle, System
+    S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt, Rm=cfg.Rm)
+    o = Oracle()
+    evals, t0, i = 0, time.perf_counter(), 0
+    out = None
+    while True:
+        w, ip, ib, xnew, xold = sets[i % len(sets)]
+        out = o.delta_action_batch(S, WF, VT, Paths, w, ip, ib, xnew, xold)
+        evals += len(w) * (cfg.Np - 1)
+        i += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    one = evals / el
+
+    # all host cores, one thread per core over disjoint item ranges (ctypes drops the GIL)
+    import threading
+    nthr = max(1, min(os.cpu_count() or 1, 64))
+    w, ip, ib, xnew, xold = sets[0]
+    chunks = np.array_split(np.arange(len(w)), nthr)
+    reps = max(1, int(4.0 * one * nthr / (len(w) * (cfg.Np - 1))))
+
+    def work(idx):
+        for _ in range(reps):
+            o.delta_action_batch(S, WF, VT, Paths, w[idx], ip[idx], ib[idx], xnew[idx], xold[idx])
+
+    th = [threading.Thread(target=work, args=(c,)) for c in chunks]
+    t1 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    allc = reps * len(w) * (cfg.Np - 1) / (time.perf_counter() - t1)
+    return dict(value=one, unit="bead-pair action evals/s", cores=1, kind="port",
+                sample="%d full-chain stages (%d items, %.2e pair evals) of the bench batch in %.1f s"
+                       % (i, i * len(sets[0][0]), evals, el),
+                all_cores=dict(value=allc, cores=nthr)), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--walkers", type=int, default=128, help="walkers per GPU")
+    ap.add_argument("--np", type=int, default=256)
+    ap.add_argument("--nb", type=int, default=80, help="reference namelist Nb (beads = 2*Nb+1)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pathintegralgroundstate_amd import SystemConfig, api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = SystemConfig(dim=3, Np=args.np, Nb=args.nb, density=0.365, dt=5e-3, Rm=1.2)
+    W = args.walkers
+    VT, WF = api.build_tables(cfg)
+    nsets = 8
+    Paths, sets = make_workload(cfg, W, nsets, seed=1982 + rank)
+
+    ctx = api.PigsContext(cfg, VT, WF, n_walkers=W, device_id=local)
+    ctx.upload_all(Paths)
+    dsets = []
+    for (w, ip, ib, xnew, xold) in sets:
+        dsets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (w, ip, ib, xnew, xold)))
+    n_items = len(sets[0][0])
+    d_out = [torch.empty(n_items, dtype=torch.float64, device=dev) for _ in range(nsets)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        w, ip, ib, xn, xo = dsets[i % nsets]
+        ctx.delta_action_batch_dev(n_items, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(),
+                                   xo.data_ptr(), d_out[i % nsets].data_ptr())
+
+    kstream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.sync()
+    est = torch.zeros(390, dtype=torch.float64, device=dev)     # block-estimator vector
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(kstream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(kstream)
+    ctx.sync()
+    if world > 1:
+        dist.all_reduce(est)                                    # RCCL, once per block
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    pair_evals_per_step = n_items * (cfg.Np - 1)
+    value = world * pair_evals_per_step * args.steps / elapsed
+    alg_bytes = n_items * (cfg.dim * cfg.Np * 8 + 2 * cfg.dim * 8 + 8)      # 6 200 B/item
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    # correctness of what was timed: rank 0 checks one stage against the oracle
+    got = d_out[0].cpu().numpy()
+    result = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu:
+            cpu, want = cpu_baseline(cfg, VT, WF, Paths, sets)
+            # `want` is the oracle's result for the last stage it ran; recompute stage 0 if different
+            from oracle.pyoracle import Oracle, System
+            S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb)
+            w, ip, ib, xnew, xold = sets[0]
+            sel = np.arange(0, n_items, 37)
+            want = Oracle().delta_action_batch(S, WF, VT, Paths, w[sel], ip[sel], ib[sel], xnew[sel], xold[sel])
+            err = np.abs(got[sel] - want) / (np.abs(want) + 1e-9 * np.max(np.abs(want)))
+            assert np.all(err < 1e-8), "bench output disagrees with the oracle: %g" % err.max()
+        result = {
+            "metric": "bead-pair action evals/sec (K1 Delta-S, N=256 Nb=161 4He, 128 walkers/GPU)",
+            "value": value, "unit": "bead-pair action evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "liquid 4He N=%d beads=%d (namelist Nb=%d), %d walkers/GPU, one full-chain "
+                                   "Delta-S stage per step (%d items x %d partners)"
+                                   % (cfg.Np, cfg.M, cfg.Nb, W, n_items, cfg.Np - 1),
+                       "walkers_per_gpu": W, "items_per_step": n_items,
+                       "stages_per_sweep_equiv": None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_delta_action<3,false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+            "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),
+        }
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
