@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--np", type=int, default=256)
     ap.add_argument("--nb", type=int, default=80, help="reference namelist Nb (beads = 2*Nb+1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--variant", type=int, default=0, help="K1 kernel variant (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,8 @@ def main():
 
     ctx = api.PigsContext(cfg, VT, WF, n_walkers=W, device_id=local)
     ctx.upload_all(Paths)
+    if args.variant:
+        ctx.set_tuning("k1_variant", args.variant)
     dsets = []
     for (w, ip, ib, xnew, xold) in sets:
         dsets.append(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (w, ip, ib, xnew, xold)))

@@ -63,6 +63,13 @@ int pigs_sync(pigs_ctx *ctx);
 /* The context's hipStream_t (as void*) so a host can order its own work against it. */
 int pigs_stream(pigs_ctx *ctx, void **hip_stream);
 
+/* Tuning knobs (performance only, never results beyond summation order).
+ *   "k1_variant": 0 auto, 1 plain, 2 short-division, 3 +LDS table, 4 +compaction, 5 +both */
+int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
+/* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
+ * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */
+int pigs_selftest_fastmath(pigs_ctx *ctx, int32_t blocks, int32_t iters, uint64_t bad[4]);
+
 /* Host-side table fill: JastrowTable / PotentialTable (vpi_mod.f90:84-145) over
  * LogPsi / Potential (system_mod.f90:38-66,136-182), including dr = rmax/real(Nmax-1)
  * and the ghost cells.  Arrays hold Nmax+2 doubles. */

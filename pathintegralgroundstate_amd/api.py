@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "pigs_commit_beads", "pigs_swap_tails", "pigs_potential_energy_slice",
     "pigs_therm_energy_batch", "pigs_local_energy_batch", "pigs_comm_unique_id",
     "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
+    "pigs_set_tuning", "pigs_selftest_fastmath",
 ]
 
 
@@ -84,6 +85,8 @@ def load_library(path=LIB_PATH):
     L.pigs_comm_init_rank.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
     L.pigs_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32]
     L.pigs_estimators_allreduce.argtypes = [vp, _dp, C.c_int32]
+    L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name != "pigs_last_error":
@@ -200,6 +203,14 @@ class PigsContext:
         s = C.c_void_p()
         _chk(self.L, self.L.pigs_stream(self.h, C.byref(s)), "pigs_stream")
         return s.value
+
+    def set_tuning(self, key, value):
+        _chk(self.L, self.L.pigs_set_tuning(self.h, key.encode(), int(value)), "pigs_set_tuning")
+
+    def selftest_fastmath(self, blocks=1024, iters=256):
+        bad = (C.c_uint64 * 4)()
+        _chk(self.L, self.L.pigs_selftest_fastmath(self.h, blocks, iters, bad), "pigs_selftest_fastmath")
+        return list(bad), blocks * 256 * iters
 
     # ---- K1
     def delta_action_batch(self, walker, ip, ib, xnew, xold):

@@ -71,6 +71,7 @@ struct pigs_ctx {
     DevBuf<int32_t> d_walker, d_ip, d_ib, d_slotw, d_slotb;
     DevBuf<double>  d_xnew, d_xold, d_out, d_parts, d_stage, d_slices, d_res;
     pigs_comm  *comm = nullptr;
+    int         k1_variant = K1_AUTO;
 };
 
 static int check_ctx(pigs_ctx *c)
@@ -129,6 +130,7 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     P.NpPad = (p->Np + 7) & ~7;
     P.trap = p->trap; P.wf_table = p->wf_table; P.v_table = p->v_table; P.nW = n_walkers;
     P.dr = p->dr; P.rcut2 = p->rcut2; P.dt = p->dt; P.Rm = p->Rm;
+    P.rdr = 1.0 / p->dr;                               // correctly rounded reciprocal (div_by)
     for (int k = 0; k < 3; ++k) {
         P.Lbox[k]     = k < p->dim ? p->Lbox[k] : 1.0;
         P.LboxHalf[k] = 0.5 * P.Lbox[k];                 // vpi.f90:118
@@ -185,6 +187,33 @@ int pigs_stream(pigs_ctx *c, void **s)
 {
     if (!c || !s) return fail(PIGS_ERR_ARG, "null pointer");
     *s = (void *)c->stream;
+    return PIGS_OK;
+}
+
+int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
+{
+    if (!c || !key) return fail(PIGS_ERR_ARG, "null pointer");
+    if (!strcmp(key, "k1_variant")) {
+        if (value < K1_AUTO || value > K1_V2_LDS_COMPACT) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
+        c->k1_variant = value;
+        return PIGS_OK;
+    }
+    return fail(PIGS_ERR_ARG, "unknown tuning key '%s'", key);
+}
+
+int pigs_selftest_fastmath(pigs_ctx *c, int32_t blocks, int32_t iters, uint64_t bad[4])
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!bad || blocks < 1 || iters < 1) return fail(PIGS_ERR_ARG, "bad arguments");
+    unsigned long long *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(launch_selftest_fastmath(c->P, 0x1234567ull, blocks, iters, d, c->stream));
+    unsigned long long h[4];
+    HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(d));
+    for (int i = 0; i < 4; ++i) bad[i] = h[i];
     return PIGS_OK;
 }
 
@@ -259,7 +288,7 @@ static int delta_action_host(pigs_ctx *c, int64_t n, const int32_t *walker, cons
     HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xnew.p, xnew, nd * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xold.p, xold, nd * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_delta_action(c->P, c->d_paths, c->d_VT, c->d_WF, (int)n, c->d_walker.p, c->d_ip.p,
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n, c->d_walker.p, c->d_ip.p,
                                c->d_ib.p, c->d_xnew.p, c->d_xold.p, c->d_out.p,
                                parts ? c->d_parts.p : nullptr, s));
     if (DeltaS) HIPCHK(hipMemcpyAsync(DeltaS, c->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -291,7 +320,7 @@ int pigs_delta_action_batch_dev(pigs_ctx *c, int64_t n, const int32_t *d_walker,
     if (n == 0) return PIGS_OK;
     if (!d_walker || !d_ip || !d_ib || !d_xnew || !d_xold || !d_DeltaS) return fail(PIGS_ERR_ARG, "null device pointer");
     // indices are range-checked on the device (out-of-range items produce NaN, never a fault)
-    HIPCHK(launch_delta_action(c->P, c->d_paths, c->d_VT, c->d_WF, (int)n, d_walker, d_ip, d_ib,
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n, d_walker, d_ip, d_ib,
                                d_xnew, d_xold, d_DeltaS, nullptr, c->stream));
     return PIGS_OK;
 }

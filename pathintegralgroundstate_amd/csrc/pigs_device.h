@@ -25,6 +25,7 @@ struct DevParams {
     int32_t v_table, nW, pad1, pad2;     // nW = resident walkers (device-side range check)
     double  dr, rcut2, dt, Rm;
     double  Lbox[3], LboxHalf[3], a_ho[3];
+    double  rdr;                         // RN(1/dr), for the exact constant division below
 };
 
 // Resident worldline layout in HBM ("bead-major, SoA inside a slice"):
@@ -105,6 +106,171 @@ __device__ __forceinline__ double interp2(const double *__restrict__ F, const Le
     double Fcurr   = (L.a1 * F[L.ix] + L.a2 * F[L.ix - 1]) / dx;           // :33
     double Fafter  = (L.a1 * F[L.ix + 1] + L.a2 * F[L.ix]) / dx;           // :34
     return (Fafter - 2.0 * Fcurr + Fbefore) / (dx * dx);                   // :36
+}
+
+// ---- exact fp64 division / sqrt in few instructions ---------------------------------------
+// The compiler's IEEE `a/b` costs ~12 instructions incl. a quarter-rate v_rcp_f64, and the hot
+// loop has up to 16 of them per bead pair.  Both forms below return the correctly rounded
+// quotient (so every term still rounds exactly like the reference's `/`):
+//   * division by a loop constant d with rd = RN(1/d) precomputed on the host (Markstein:
+//     q=a*rd; r=fma(-q,d,a); q'=fma(r,rd,q) is RN(a/d) when rd is the correctly rounded
+//     reciprocal);
+//   * several divisions by the same r sharing one refined reciprocal y ~ 1/r (error << 1 ulp):
+//     the same residual-correction step, which is also how the compiler's own expansion ends.
+// Operands here are normal-range (0 < r <= rcut, |numerators| far from over/underflow), so the
+// v_div_scale / v_div_fixup range handling of the general expansion is not needed; NaN/Inf
+// inputs still propagate to NaN.  pigs_selftest_fastmath() checks both against `/` and sqrt()
+// bit for bit on the GPU.
+__device__ __forceinline__ double div_by(double a, double d, double rd)
+{
+    const double q = a * rd;
+    const double r = __builtin_fma(-q, d, a);
+    return __builtin_fma(r, rd, q);
+}
+
+// s = RN(sqrt(x)) and y ~ 1/s from ONE v_rsq_f64 seed (Goldschmidt step + residual corrections).
+__device__ __forceinline__ void sqrt_rinv(double x, double &s, double &y)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0;
+    double h = 0.5 * y0;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d1, h, g);
+    s = g;
+    double yy = h + h;
+    const double e = __builtin_fma(-g, yy, 1.0);
+    y = __builtin_fma(e, yy, yy);
+}
+
+__device__ __forceinline__ double sqrt_exact(double x)
+{
+    double s, y;
+    sqrt_rinv(x, s, y);
+    return s;
+}
+
+// table lookup with the exact constant division (same results as lerp_setup/interp* above)
+struct FLerp {
+    int    ix, im2;
+    double a1, a2;
+};
+
+__device__ __forceinline__ FLerp flerp_setup(double x, const DevParams &P)
+{
+    FLerp L;
+    const int ix = (int)div_by(x, P.dr, P.rdr) + 1;
+    L.a1  = x - (double)(ix - 1) * P.dr;
+    L.a2  = P.dr - L.a1;
+    L.ix  = min(ix, P.Nmax);
+    L.im2 = max(L.ix - 2, 0);
+    return L;
+}
+
+template <typename TabPtr>
+__device__ __forceinline__ double finterp0(TabPtr F, const FLerp &L, const DevParams &P)
+{
+    return div_by(L.a1 * F[L.ix] + L.a2 * F[L.ix - 1], P.dr, P.rdr);
+}
+
+template <typename TabPtr>
+__device__ __forceinline__ void finterp01(TabPtr F, const FLerp &L, const DevParams &P, double &v0, double &v1)
+{
+    const double fm2 = F[L.im2], fm1 = F[L.ix - 1], f0 = F[L.ix], fp1 = F[L.ix + 1];
+    v0 = div_by(L.a1 * f0 + L.a2 * fm1, P.dr, P.rdr);
+    const double Fbefore = div_by(L.a1 * fm1 + L.a2 * fm2, P.dr, P.rdr);
+    const double Fafter  = div_by(L.a1 * fp1 + L.a2 * f0, P.dr, P.rdr);
+    v1 = div_by(0.5 * (Fafter - Fbefore), P.dr, P.rdr);
+}
+
+// ---- minimum image, branch-free form: d - copysign(L,d) where |d| > L/2.  Identical to the
+// two compares of pbc_mod.f90:40-41 for every input (x+L == x-(-L); the second wrap can never
+// follow the first because LboxHalf == L/2 exactly); NaN stays NaN.
+template <int DIM>
+__device__ __forceinline__ double min_image_fast(double (&x)[DIM], const DevParams &P)
+{
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const double v = x[k];
+        const double w = v - __builtin_copysign(P.Lbox[k], v);
+        const double u = (__builtin_fabs(v) > P.LboxHalf[k]) ? w : v;
+        x[k] = u;
+        r2 = r2 + u * u;
+    }
+    return r2;
+}
+
+// ---- several accumulators reduced over the wave with one shared butterfly: at each of the
+// first log2(N) steps a lane keeps half of its values and ships the other half, so N values
+// cost N-1 + (6-log2 N) shuffles instead of 6N.  Afterwards value i's total sits in every
+// lane whose bits {32,16,8,...} spell i (MSB first); lane_of(i) gives one such lane.
+template <int N>
+__device__ __forceinline__ void wave_reduce_multi(double (&v)[N], int lane)
+{
+    int stride = 32;
+#pragma unroll
+    for (int cnt = N; cnt > 1; cnt >>= 1, stride >>= 1) {
+        const bool upper = (lane & stride) != 0;
+#pragma unroll
+        for (int i = 0; i < cnt / 2; ++i) {
+            const double send = upper ? v[i] : v[i + cnt / 2];
+            const double keep = upper ? v[i + cnt / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, stride, kWave);
+        }
+    }
+#pragma unroll
+    for (; stride >= 1; stride >>= 1) v[0] += __shfl_xor(v[0], stride, kWave);
+}
+
+// ---- N accumulators x 64 lanes summed through a per-wave LDS transpose ---------------------
+// scratch: N rows of kRedStride doubles (stride 65 keeps both the row writes and the strided
+// reads bank-conflict free).  Each lane first adds up N entries of value (lane % N), then the
+// 64/N partials per value are folded with log2(64/N) shuffles: ~3N+5*log2(64/N) instructions
+// instead of ~50 per value for a plain butterfly.  Afterwards every lane l holds the total of
+// value l % N.  DS instructions of one wave execute in issue order, so no barrier is needed
+// between the writes and the reads (wave_barrier only pins the compiler's order).
+constexpr int kRedStride = 65;
+
+template <int N>
+__device__ __forceinline__ double wave_reduce_lds(const double (&v)[N], double *scratch, int lane)
+{
+    static_assert(N == 2 || N == 4 || N == 8, "N must divide 64");
+#pragma unroll
+    for (int i = 0; i < N; ++i) scratch[i * kRedStride + lane] = v[i];
+    __builtin_amdgcn_wave_barrier();
+    const int vi = lane % N, g = lane / N;
+    const double *row = scratch + vi * kRedStride + g * N;
+    double s = row[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) s = s + row[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int stride = N; stride < kWave; stride <<= 1) s = s + __shfl_xor(s, stride, kWave);
+    return s;
+}
+
+template <int N>
+__device__ __forceinline__ constexpr int lane_of(int i)
+{
+    // bits of i, MSB first, land on lane bits 32,16,8,...
+    int lane = 0, stride = 32;
+    for (int cnt = N; cnt > 1; cnt >>= 1, stride >>= 1)
+        if (i & (cnt >> 1)) lane |= stride;
+    return lane;
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
 }
 
 // ---- Chin weights (global_mod.f90:19-72) -------------------------------------------

@@ -1,0 +1,554 @@
+// pigs_k1.hip -- K1: batched Delta S of proposal beads on gfx950.
+//
+// Replaces the reference's `call UpdateAction` (vpi_mod.f90:2491-2530) with its callees
+// UpdatePot (2660-2841), UpdateWf (2534-2656) and GreenFunction opt 0 (global_mod.f90:19-72),
+// batched over (walker, particle, bead) proposal items.
+//
+// Work decomposition: ONE wave64 per item (an item's 255 partners are 4 lane-strided passes
+// over one contiguous 6 KB SoA slice: 512-B coalesced loads per coordinate); no workgroup
+// barrier anywhere in the item loop.  The kernel is instruction-issue bound on fp64 VALU
+// (sqrt + up to 8 divisions per distance), not on HBM, so the variants attack instruction
+// count and lane utilisation:
+//   v1  plain statement (IEEE `/`, sqrt(), tables gathered from global memory)
+//   v2  exact short division / fused sqrt+1/r (pigs_device.h), one shared butterfly for all
+//       accumulators; template flags:
+//         LDSTAB   VTable resident in LDS (80 KB): gathers become ds_read_b64
+//         COMPACT  two passes: (1) distances + cutoff test for all partners, in-cutoff
+//                  (partner, new|old) codes compacted through LDS with ballot/mbcnt;
+//                  (2) the expensive part runs on dense lanes only (44 % of the distance
+//                  evaluations are outside rcut and would otherwise idle their lanes).
+// Every variant sums bit-identical per-pair terms; only the summation order differs.
+#include "pigs_device.h"
+#include "pigs_kernels.h"
+
+namespace pigs {
+
+// =====================================================================================
+// K1 v1 (plain form, kept as the readable reference of the kernel and for A/B timing):
+// one wave64 per proposal item; lane l visits partners jp = l, l+64, ... of the
+// item's slice (unit-stride 512-B loads per coordinate), accumulates its partial sums
+// in registers, then one butterfly per accumulator.  Wave-uniform control flow per item
+// (bead parity / end bead), so no divergence except the physical cutoff test.
+// Algorithmic bytes per item: dim*Np*8 (slice) + 2*dim*8 (xnew,xold) + 8 (DeltaS)
+// (+12 B of indices), i.e. 6 200 B at Np=256 for Np-1=255 bead-pair evaluations.
+// =====================================================================================
+template <int DIM, bool TRAP>
+__global__ __launch_bounds__(256) void k_delta_action_v1(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = threadIdx.x >> 6;
+    const int nwave = gridDim.x * (blockDim.x >> 6);
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+
+    for (int item = blockIdx.x * (blockDim.x >> 6) + wid; item < n_items; item += nwave) {
+        const int it = __builtin_amdgcn_readfirstlane(item);
+        const int w  = walker[it];
+        const int p  = ipv[it] - 1;          // 0-based moved particle
+        const int b  = ibv[it];
+        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
+            if (lane == 0) out[it] = __builtin_nan("");      // bad index: never touch memory with it
+            continue;
+        }
+        double xn[DIM], xo[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xn[k] = xnew[(size_t)it * DIM + k];
+            xo[k] = xold[(size_t)it * DIM + k];
+        }
+        const double *S   = paths + ((size_t)w * P.M + b) * sl;
+        const bool odd    = (b & 1) != 0;                    // UpdateAction: force term on odd beads
+        const bool endb   = (b == 0) || (b == 2 * P.Nb);     // UpdateWf only on the two end beads
+
+        double potN = 0.0, potO = 0.0, psiN = 0.0, psiO = 0.0;
+        double fN[DIM], fO[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { fN[k] = 0.0; fO[k] = 0.0; }
+
+        if (TRAP && lane == 0) {                              // vpi_mod.f90:2688-2695, 2555-2560
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                potN = potN + trap_pot(0, P.a_ho[k], xn[k]);
+                potO = potO + trap_pot(0, P.a_ho[k], xo[k]);
+                fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
+                fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
+                if (endb) {
+                    psiO = psiO + trap_psi(0, P.a_ho[k], xo[k]);
+                    psiN = psiN + trap_psi(0, P.a_ho[k], xn[k]);
+                }
+            }
+        }
+
+        for (int j0 = 0; j0 < P.Np; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < P.Np && j != p) {                        // vpi_mod.f90:2699: never read row ip
+                double dnew[DIM], dold[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                    const double rj = S[(size_t)k * P.NpPad + j];
+                    dnew[k] = xn[k] - rj;                      // :2706
+                    dold[k] = xo[k] - rj;                      // :2707
+                }
+                double r2n, r2o;
+                if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+                else      { r2o = min_image<DIM>(dold, P); r2n = min_image<DIM>(dnew, P); }
+
+                if (TRAP || r2n <= P.rcut2) {                // :2723 (Q5) / :2771
+                    const double r = sqrt(r2n);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    potN = potN + interp0(VT, L, P.dr);
+                    if (odd) {
+                        const double dv = interp1(VT, L, P.dr);
+#pragma unroll
+                        for (int k = 0; k < DIM; ++k) fN[k] = fN[k] + dv * dnew[k] / r;   // :2784
+                    }
+                    if (endb) psiN = psiN + interp0(WF, L, P.dr);                       // :2638
+                }
+                if (r2o <= P.rcut2) {                        // :2745 / :2795
+                    const double r = sqrt(r2o);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    potO = potO + interp0(VT, L, P.dr);
+                    if (odd) {
+                        const double dv = interp1(VT, L, P.dr);
+#pragma unroll
+                        for (int k = 0; k < DIM; ++k) fO[k] = fO[k] + dv * dold[k] / r;   // :2808
+                    }
+                    if (endb) psiO = psiO + interp0(WF, L, P.dr);                       // :2624
+                } else if (TRAP && endb) {
+                    // UpdateWf's trap branch has no cutoff on either distance (vpi_mod.f90:2595-2615)
+                    const double r = sqrt(r2o);
+                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
+                    psiO = psiO + interp0(WF, L, P.dr);
+                }
+            }
+        }
+
+        potN = wave_sum(potN);
+        potO = wave_sum(potO);
+        double dF2 = 0.0, dPsi = 0.0;
+        if (odd) {
+            double fn2 = 0.0, fo2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                const double a = wave_sum(fN[k]);
+                const double c = wave_sum(fO[k]);
+                fn2 = fn2 + a * a;                            // :2831
+                fo2 = fo2 + c * c;                            // :2832
+            }
+            dF2 = fn2 - fo2;                                  // :2835
+        }
+        if (endb) {
+            psiN = wave_sum(psiN);
+            psiO = wave_sum(psiO);
+            dPsi = psiN - psiO;                               // :2653
+        }
+        if (lane == 0) {
+            const double dPot = potN - potO;                  // :2838
+            out[it] = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527
+            if (parts) {
+                parts[(size_t)it * 3 + 0] = dPot;
+                parts[(size_t)it * 3 + 1] = dF2;
+                parts[(size_t)it * 3 + 2] = dPsi;
+            }
+        }
+    }
+}
+
+
+// =====================================================================================
+// K1 v2
+// =====================================================================================
+namespace {
+
+constexpr int kWaveLds = 8 * kRedStride * (int)sizeof(double);   // 4160 B per wave
+
+// bead classes of UpdateAction (vpi_mod.f90:2509-2525): what is accumulated per pair
+enum BeadClass { CLS_EVEN = 0, CLS_ODD = 1, CLS_END = 2 };
+
+// per-lane accumulators of one item
+template <int DIM, int CLS>
+struct Acc {
+    double potN = 0.0, potO = 0.0;
+    double psiN = 0.0, psiO = 0.0;      // CLS_END only
+    double fN[DIM], fO[DIM];            // CLS_ODD only
+    __device__ __forceinline__ Acc()
+    {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { fN[k] = 0.0; fO[k] = 0.0; }
+    }
+};
+
+// in-cutoff work of ONE distance: table cell, V (opt 0), dV/dr (opt 1) and the force terms
+// (dv*xij(k))/rij on odd beads, u (opt 0 of LogWF) on end beads.
+template <int DIM, int CLS, bool IS_OLD, typename VTab>
+__device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                                double r2, const double (&d)[DIM], Acc<DIM, CLS> &A,
+                                                bool pot_on = true)
+{
+    double r, rinv;
+    sqrt_rinv(r2, r, rinv);
+    const FLerp L = flerp_setup(r, P);
+    if (CLS == CLS_ODD) {
+        double v, dv;
+        finterp01(VT, L, P, v, dv);
+        if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double f = div_by(dv * d[k], r, rinv);            // (dv*xij(k))/rij
+            if (IS_OLD) A.fO[k] = A.fO[k] + f; else A.fN[k] = A.fN[k] + f;
+        }
+    } else {
+        if (pot_on) {
+            const double v = finterp0(VT, L, P);
+            if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
+        }
+        if (CLS == CLS_END) {
+            const double u = finterp0(WF, L, P);
+            if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
+        }
+    }
+}
+
+// reduce the class's accumulators over the wave, apply the Chin weight, store
+template <int DIM, int CLS>
+__device__ __forceinline__ void finish_item(const DevParams &P, int lane, int it, int b, const Acc<DIM, CLS> &A,
+                                            double *red, double *__restrict__ out, double *__restrict__ parts)
+{
+    double dPot, dF2 = 0.0, dPsi = 0.0;
+    if (CLS == CLS_ODD) {
+        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
+        const double t = wave_reduce_lds<8>(v, red, lane);
+        double fn2 = 0.0, fo2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double a = read_lane(t, 2 + k);
+            const double c = read_lane(t, 5 + k);
+            fn2 = fn2 + a * a;                                      // vpi_mod.f90:2831-2832
+            fo2 = fo2 + c * c;
+        }
+        dPot = read_lane(t, 0) - read_lane(t, 1);                   // :2838
+        dF2  = fn2 - fo2;                                           // :2835
+    } else if (CLS == CLS_END) {
+        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
+        const double t = wave_reduce_lds<4>(v, red, lane);
+        dPot = read_lane(t, 0) - read_lane(t, 1);
+        dPsi = read_lane(t, 2) - read_lane(t, 3);                   // :2653
+    } else {
+        const double v[2] = {A.potN, A.potO};
+        const double t = wave_reduce_lds<2>(v, red, lane);
+        dPot = read_lane(t, 0) - read_lane(t, 1);
+    }
+    if (lane == 0) {
+        out[it] = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527
+        if (parts) {
+            parts[(size_t)it * 3 + 0] = dPot;
+            parts[(size_t)it * 3 + 1] = dF2;
+            parts[(size_t)it * 3 + 2] = dPsi;
+        }
+    }
+}
+
+// one item, every partner visited by its lane (no compaction)
+template <int DIM, bool TRAP, int CLS, typename VTab>
+__device__ __forceinline__ void item_direct(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                            const double *__restrict__ S, int p, const double (&xn)[DIM],
+                                            const double (&xo)[DIM], int lane, int it, int b, double *red,
+                                            double *__restrict__ out, double *__restrict__ parts)
+{
+    Acc<DIM, CLS> A;
+    if (TRAP && lane == 0) {                                          // vpi_mod.f90:2688-2695, 2555-2560
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            A.potN = A.potN + trap_pot(0, P.a_ho[k], xn[k]);
+            A.potO = A.potO + trap_pot(0, P.a_ho[k], xo[k]);
+            if (CLS == CLS_ODD) {
+                A.fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
+                A.fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
+            }
+            if (CLS == CLS_END) {
+                A.psiO = A.psiO + trap_psi(0, P.a_ho[k], xo[k]);
+                A.psiN = A.psiN + trap_psi(0, P.a_ho[k], xn[k]);
+            }
+        }
+    }
+    for (int j0 = 0; j0 < P.Np; j0 += kWave) {
+        const int j = j0 + lane;
+        if (j < P.Np && j != p) {                                     // :2699: row ip is never read
+            double dnew[DIM], dold[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                const double rj = S[(size_t)k * P.NpPad + j];
+                dnew[k] = xn[k] - rj;                                 // :2706-2707
+                dold[k] = xo[k] - rj;
+            }
+            double r2n, r2o;
+            if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+            else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
+            if (TRAP || r2n <= P.rcut2)                               // :2723 (Q5) / :2771
+                pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
+            const bool in_o = r2o <= P.rcut2;                         // :2745 / :2795
+            if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
+            else if (TRAP && CLS == CLS_END)                          // UpdateWf's trap branch has no cutoff
+                pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
+        }
+    }
+    finish_item<DIM, CLS>(P, lane, it, b, A, red, out, parts);
+}
+
+// one item in two passes: (1) all distances + cutoff, in-cutoff (partner, new|old) codes compacted
+// into the wave's LDS list with ballot/mbcnt; (2) dense lanes re-derive their distance and do the
+// expensive part.  PBC only (TRAP has no cutoff on the new distance), Np <= 256.
+template <int DIM, int CLS, typename VTab>
+__device__ __forceinline__ void item_compact(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                             const double *__restrict__ S, int p, const double (&xn)[DIM],
+                                             const double (&xo)[DIM], int lane, int it, int b,
+                                             unsigned short *codes, double *red,
+                                             double *__restrict__ out, double *__restrict__ parts)
+{
+    Acc<DIM, CLS> A;
+    const int npass = (P.Np + kWave - 1) / kWave;
+    int count = 0;                                                    // wave-uniform
+    for (int m = 0; m < npass; ++m) {
+        const int j = m * kWave + lane;
+        const bool valid = j < P.Np && j != p;
+        double dnew[DIM], dold[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double rj = valid ? S[(size_t)k * P.NpPad + j] : 0.0;
+            dnew[k] = xn[k] - rj;
+            dold[k] = xo[k] - rj;
+        }
+        const double r2n = min_image_fast<DIM>(dnew, P);
+        const double r2o = min_image_fast<DIM>(dold, P);
+        const bool in_n = valid && r2n <= P.rcut2;
+        const bool in_o = valid && r2o <= P.rcut2;
+        const unsigned long long bn = __ballot(in_n);
+        const unsigned long long bo = __ballot(in_o);
+        const int pn = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bn, 0));
+        count += __builtin_popcountll(bn);
+        const int po = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bo, 0));
+        count += __builtin_popcountll(bo);
+        const unsigned short code = (unsigned short)(((m << 1) << 6) | lane);
+        if (in_n) codes[pn] = code;
+        if (in_o) codes[po] = code | (1u << 6);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < count; t0 += kWave) {
+        const int idx = t0 + lane;
+        if (idx < count) {
+            const unsigned c = codes[idx];
+            const bool is_old = (c >> 6) & 1u;
+            const int j = (int)(c >> 7) * kWave + (int)(c & 63u);
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = (is_old ? xo[k] : xn[k]) - S[(size_t)k * P.NpPad + j];
+            const double r2 = min_image_fast<DIM>(d, P);
+            if (is_old) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2, d, A);
+            else        pair_accumulate<DIM, CLS, false>(P, VT, WF, r2, d, A);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    finish_item<DIM, CLS>(P, lane, it, b, A, red, out, parts);
+}
+
+} // namespace
+
+// LDS layout (dynamic): [VTable copy: Nmax+2 doubles, if LDSTAB][per wave: kWaveLds bytes = reduction
+// scratch (8 x 65 doubles), whose head doubles as the 512 x u16 code list of COMPACT]
+template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = threadIdx.x >> 6;
+    const int nwave = gridDim.x * (BLOCK >> 6);
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+
+    const double *VT = VTg;
+    size_t off = 0;
+    if (LDSTAB) {
+        double *tab = reinterpret_cast<double *>(smem);
+        const int nt = P.Nmax + 2;
+        for (int t = threadIdx.x; t < nt; t += BLOCK) tab[t] = VTg[t];
+        off = ((size_t)nt * sizeof(double) + 15) & ~(size_t)15;
+        __syncthreads();
+        VT = tab;
+    }
+    unsigned char *wave_lds = smem + off + (size_t)wid * kWaveLds;
+    unsigned short *codes = reinterpret_cast<unsigned short *>(wave_lds);
+    double *red = reinterpret_cast<double *>(wave_lds);
+
+    for (int item = blockIdx.x * (BLOCK >> 6) + wid; item < n_items; item += nwave) {
+        const int it = __builtin_amdgcn_readfirstlane(item);
+        const int w  = walker[it];
+        const int p  = ipv[it] - 1;
+        const int b  = ibv[it];
+        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
+            if (lane == 0) out[it] = __builtin_nan("");
+            continue;
+        }
+        double xn[DIM], xo[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xn[k] = xnew[(size_t)it * DIM + k];
+            xo[k] = xold[(size_t)it * DIM + k];
+        }
+        const double *S = paths + ((size_t)w * P.M + b) * sl;
+        const bool odd  = (b & 1) != 0;                         // UpdateAction: force term on odd beads
+        const bool endb = (b == 0) || (b == 2 * P.Nb);          // UpdateWf only on the two end beads
+        if (COMPACT && !TRAP) {
+            if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
+            else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
+            else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
+        } else {
+            if (odd)       item_direct<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
+            else if (endb) item_direct<DIM, TRAP, CLS_END>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
+            else           item_direct<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
+        }
+    }
+}
+
+// bit-for-bit check of the short division / sqrt forms against the compiler's IEEE ones
+__global__ void k_selftest_fastmath(DevParams P, unsigned long long seed, int iters, unsigned long long *bad)
+{
+    unsigned long long s = seed ^ (0x9E3779B97F4A7C15ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1));
+    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    for (int i = 0; i < iters; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u1 = (double)(s >> 11) * (1.0 / 9007199254740992.0);
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u2 = (double)(s >> 11) * (1.0 / 9007199254740992.0);
+        const double rmax2 = 4.0 * P.rcut2;
+        const double x = (i & 1) ? u1 * rmax2 : u1 * u1 * 1e-3 + 1e-12;       // r^2 samples
+        double sq, y;
+        sqrt_rinv(x, sq, y);
+        if (sq != sqrt(x)) ++b0;
+        const double num = (u2 - 0.5) * ((i & 2) ? 1e6 : 3.0);
+        if (div_by(num, sq, y) != num / sq) ++b1;
+        if (div_by(sq, P.dr, P.rdr) != sq / P.dr) ++b2;
+        if (div_by(num, P.dr, P.rdr) != num / P.dr) ++b3;
+    }
+    atomicAdd(&bad[0], b0); atomicAdd(&bad[1], b1); atomicAdd(&bad[2], b2); atomicAdd(&bad[3], b3);
+}
+
+// =====================================================================================
+// launcher
+// =====================================================================================
+#define PIGS_DISPATCH(P, CALL)                                              \
+    do {                                                                    \
+        if ((P).trap) {                                                     \
+            if ((P).dim == 1) { CALL(1, true); }                            \
+            else if ((P).dim == 2) { CALL(2, true); }                       \
+            else { CALL(3, true); }                                         \
+        } else {                                                            \
+            if ((P).dim == 1) { CALL(1, false); }                           \
+            else if ((P).dim == 2) { CALL(2, false); }                      \
+            else { CALL(3, false); }                                        \
+        }                                                                   \
+    } while (0)
+
+static int k1_grid(int n_items, int waves_per_block, int cap_blocks)
+{
+    int blocks = (n_items + waves_per_block - 1) / waves_per_block;
+    return blocks < cap_blocks ? (blocks > 0 ? blocks : 1) : cap_blocks;
+}
+
+template <typename K>
+static hipError_t set_lds(K kern, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,
+                               const double *WF, int n_items, const int32_t *walker,
+                               const int32_t *ip, const int32_t *ib, const double *xnew,
+                               const double *xold, double *out, double *parts, hipStream_t st)
+{
+    if (n_items <= 0) return hipSuccess;
+    const size_t tab_bytes  = (((size_t)(P.Nmax + 2) * sizeof(double)) + 15) & ~(size_t)15;
+    const bool can_compact  = !P.trap && P.Np <= 256;          // 8 code slots per lane
+    const bool can_ldstab   = tab_bytes + 16 * kWaveLds <= 160 * 1024;
+    if (variant == K1_AUTO) variant = K1_V2;
+    if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
+    if ((variant == K1_V2_LDS || variant == K1_V2_LDS_COMPACT) && !can_ldstab) variant = K1_V2;
+    hipError_t e = hipSuccess;
+    switch (variant) {
+    case K1_V1: {
+#define CALL(D, T)                                                                              \
+    hipLaunchKernelGGL((k_delta_action_v1<D, T>), dim3(k1_grid(n_items, 4, 2048)), dim3(256), 0, st, P, \
+                       paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_V2: {
+        const size_t lds = 4 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256>), dim3(k1_grid(n_items, 4, 1 << 22)),   \
+                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_V2_COMPACT: {
+        const size_t lds = 4 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    hipLaunchKernelGGL((k_delta_action_v2<D, false, false, true, 256>), dim3(k1_grid(n_items, 4, 1 << 22)), \
+                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_V2_LDS: {
+        const size_t lds = tab_bytes + 16 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    do {                                                                                                \
+        e = set_lds(k_delta_action_v2<D, T, true, false, 1024>, lds);                                   \
+        if (e == hipSuccess)                                                                            \
+            hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024>), dim3(k1_grid(n_items, 16, 256)), \
+                               dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
+    } while (0)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_V2_LDS_COMPACT: {
+        const size_t lds = tab_bytes + 16 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    do {                                                                                                \
+        e = set_lds(k_delta_action_v2<D, false, true, true, 1024>, lds);                                \
+        if (e == hipSuccess)                                                                            \
+            hipLaunchKernelGGL((k_delta_action_v2<D, false, true, true, 1024>), dim3(k1_grid(n_items, 16, 256)), \
+                               dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
+    } while (0)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    default:
+        return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
+                                    unsigned long long *d_bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_fastmath, dim3(blocks), dim3(256), 0, st, P, seed, iters, d_bad);
+    return hipGetLastError();
+}
+
+} // namespace pigs

@@ -9,7 +9,17 @@
 
 namespace pigs {
 
-hipError_t launch_delta_action(const DevParams &P, const double *paths, const double *VT,
+// K1 kernel variants (pigs_k1.hip)
+enum K1Variant {
+    K1_AUTO = 0,            // library's choice
+    K1_V1 = 1,              // plain statement
+    K1_V2 = 2,              // exact short division, fused sqrt/rinv, shared butterfly
+    K1_V2_LDS = 3,          // + VTable in LDS
+    K1_V2_COMPACT = 4,      // + in-cutoff compaction (global table)
+    K1_V2_LDS_COMPACT = 5   // + both
+};
+
+hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,
                                const double *WF, int n_items, const int32_t *walker,
                                const int32_t *ip, const int32_t *ib, const double *xnew,
                                const double *xold, double *out, double *parts, hipStream_t st);
@@ -30,6 +40,9 @@ hipError_t launch_commit_beads(const DevParams &P, double *paths, int64_t n, con
 
 hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int iw, int ik,
                              hipStream_t st);
+
+hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
+                                    unsigned long long *d_bad, hipStream_t st);
 
 hipError_t launch_pack(const DevParams &P, double *paths, const double *raw, int w0, int nw,
                        hipStream_t st);

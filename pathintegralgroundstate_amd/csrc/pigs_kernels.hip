@@ -1,6 +1,6 @@
 // pigs_kernels.hip -- hand-written gfx950 kernels of the PIGS action / energy hot path.
 //
-//   K1  k_delta_action   batched Delta S of proposal beads      (vpi_mod.f90:2491-2841)
+//   K1  (pigs_k1.hip)    batched Delta S of proposal beads      (vpi_mod.f90:2491-2841)
 //   K2  k_slice_energy   per-slice V, sum_i|F_i|^2 (+ K3 spring) (sample_mod.f90:13-150,359-380)
 //   K3' k_therm_combine  Chin-weighted combine per walker        (sample_mod.f90:344-385)
 //   K4  k_local_energy   Jastrow local energy of one slice       (sample_mod.f90:154-319)
@@ -13,140 +13,6 @@
 #include "pigs_kernels.h"
 
 namespace pigs {
-
-// =====================================================================================
-// K1: one wave64 per proposal item; lane l visits partners jp = l, l+64, ... of the
-// item's slice (unit-stride 512-B loads per coordinate), accumulates its partial sums
-// in registers, then one butterfly per accumulator.  Wave-uniform control flow per item
-// (bead parity / end bead), so no divergence except the physical cutoff test.
-// Algorithmic bytes per item: dim*Np*8 (slice) + 2*dim*8 (xnew,xold) + 8 (DeltaS)
-// (+12 B of indices), i.e. 6 200 B at Np=256 for Np-1=255 bead-pair evaluations.
-// =====================================================================================
-template <int DIM, bool TRAP>
-__global__ __launch_bounds__(256) void k_delta_action(
-    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
-    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
-    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
-    const double *__restrict__ xnew, const double *__restrict__ xold,
-    double *__restrict__ out, double *__restrict__ parts)
-{
-    const int lane  = threadIdx.x & (kWave - 1);
-    const int wid   = threadIdx.x >> 6;
-    const int nwave = gridDim.x * (blockDim.x >> 6);
-    const size_t sl = slice_doubles(DIM, P.NpPad);
-
-    for (int item = blockIdx.x * (blockDim.x >> 6) + wid; item < n_items; item += nwave) {
-        const int it = __builtin_amdgcn_readfirstlane(item);
-        const int w  = walker[it];
-        const int p  = ipv[it] - 1;          // 0-based moved particle
-        const int b  = ibv[it];
-        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
-            if (lane == 0) out[it] = __builtin_nan("");      // bad index: never touch memory with it
-            continue;
-        }
-        double xn[DIM], xo[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            xn[k] = xnew[(size_t)it * DIM + k];
-            xo[k] = xold[(size_t)it * DIM + k];
-        }
-        const double *S   = paths + ((size_t)w * P.M + b) * sl;
-        const bool odd    = (b & 1) != 0;                    // UpdateAction: force term on odd beads
-        const bool endb   = (b == 0) || (b == 2 * P.Nb);     // UpdateWf only on the two end beads
-
-        double potN = 0.0, potO = 0.0, psiN = 0.0, psiO = 0.0;
-        double fN[DIM], fO[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) { fN[k] = 0.0; fO[k] = 0.0; }
-
-        if (TRAP && lane == 0) {                              // vpi_mod.f90:2688-2695, 2555-2560
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                potN = potN + trap_pot(0, P.a_ho[k], xn[k]);
-                potO = potO + trap_pot(0, P.a_ho[k], xo[k]);
-                fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
-                fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
-                if (endb) {
-                    psiO = psiO + trap_psi(0, P.a_ho[k], xo[k]);
-                    psiN = psiN + trap_psi(0, P.a_ho[k], xn[k]);
-                }
-            }
-        }
-
-        for (int j0 = 0; j0 < P.Np; j0 += kWave) {
-            const int j = j0 + lane;
-            if (j < P.Np && j != p) {                        // vpi_mod.f90:2699: never read row ip
-                double dnew[DIM], dold[DIM];
-#pragma unroll
-                for (int k = 0; k < DIM; ++k) {
-                    const double rj = S[(size_t)k * P.NpPad + j];
-                    dnew[k] = xn[k] - rj;                      // :2706
-                    dold[k] = xo[k] - rj;                      // :2707
-                }
-                double r2n, r2o;
-                if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
-                else      { r2o = min_image<DIM>(dold, P); r2n = min_image<DIM>(dnew, P); }
-
-                if (TRAP || r2n <= P.rcut2) {                // :2723 (Q5) / :2771
-                    const double r = sqrt(r2n);
-                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
-                    potN = potN + interp0(VT, L, P.dr);
-                    if (odd) {
-                        const double dv = interp1(VT, L, P.dr);
-#pragma unroll
-                        for (int k = 0; k < DIM; ++k) fN[k] = fN[k] + dv * dnew[k] / r;   // :2784
-                    }
-                    if (endb) psiN = psiN + interp0(WF, L, P.dr);                       // :2638
-                }
-                if (r2o <= P.rcut2) {                        // :2745 / :2795
-                    const double r = sqrt(r2o);
-                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
-                    potO = potO + interp0(VT, L, P.dr);
-                    if (odd) {
-                        const double dv = interp1(VT, L, P.dr);
-#pragma unroll
-                        for (int k = 0; k < DIM; ++k) fO[k] = fO[k] + dv * dold[k] / r;   // :2808
-                    }
-                    if (endb) psiO = psiO + interp0(WF, L, P.dr);                       // :2624
-                } else if (TRAP && endb) {
-                    // UpdateWf's trap branch has no cutoff on either distance (vpi_mod.f90:2595-2615)
-                    const double r = sqrt(r2o);
-                    const Lerp L = lerp_setup(r, P.dr, P.Nmax);
-                    psiO = psiO + interp0(WF, L, P.dr);
-                }
-            }
-        }
-
-        potN = wave_sum(potN);
-        potO = wave_sum(potO);
-        double dF2 = 0.0, dPsi = 0.0;
-        if (odd) {
-            double fn2 = 0.0, fo2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                const double a = wave_sum(fN[k]);
-                const double c = wave_sum(fO[k]);
-                fn2 = fn2 + a * a;                            // :2831
-                fo2 = fo2 + c * c;                            // :2832
-            }
-            dF2 = fn2 - fo2;                                  // :2835
-        }
-        if (endb) {
-            psiN = wave_sum(psiN);
-            psiO = wave_sum(psiO);
-            dPsi = psiN - psiO;                               // :2653
-        }
-        if (lane == 0) {
-            const double dPot = potN - potO;                  // :2838
-            out[it] = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527
-            if (parts) {
-                parts[(size_t)it * 3 + 0] = dPot;
-                parts[(size_t)it * 3 + 1] = dF2;
-                parts[(size_t)it * 3 + 2] = dPsi;
-            }
-        }
-    }
-}
 
 // =====================================================================================
 // K2 (+K3): one workgroup per (walker, slice).  The slice is staged once in LDS (SoA);
@@ -417,28 +283,6 @@ __global__ void k_unpack(DevParams P, const double *__restrict__ paths, double *
             else { CALL(3, false); }                                        \
         }                                                                   \
     } while (0)
-
-static int k1_grid(int n_items)
-{
-    const int per_block = 4;                         // waves (items in flight) per workgroup
-    int blocks = (n_items + per_block - 1) / per_block;
-    const int cap = 256 * 8;                         // 256 CUs x 8 workgroups of 256 threads
-    return blocks < cap ? (blocks > 0 ? blocks : 1) : cap;
-}
-
-hipError_t launch_delta_action(const DevParams &P, const double *paths, const double *VT,
-                               const double *WF, int n_items, const int32_t *walker,
-                               const int32_t *ip, const int32_t *ib, const double *xnew,
-                               const double *xold, double *out, double *parts, hipStream_t st)
-{
-    if (n_items <= 0) return hipSuccess;
-#define CALL(D, T)                                                                         \
-    hipLaunchKernelGGL((k_delta_action<D, T>), dim3(k1_grid(n_items)), dim3(256), 0, st, P, \
-                       paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
-    PIGS_DISPATCH(P, CALL);
-#undef CALL
-    return hipGetLastError();
-}
 
 static int slice_block(const DevParams &P)
 {

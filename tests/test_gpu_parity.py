@@ -105,6 +105,38 @@ def test_external_tables_vs_golden(gpu_lib, tag):
     assert _close_rel([E[0], Ec[0], Ep[0]], d["therm"])
 
 
+def test_short_division_and_sqrt_are_exact(gpu_lib):
+    """The kernels' 3-instruction division / fused sqrt forms are bit-identical to IEEE `/` and
+    sqrt() (so per-pair terms stay bit-identical to the reference's): 2.7e8 random operands."""
+    t = load_golden("tables_he4_n256")
+    cfg = config_from_golden(t)
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=1) as ctx:
+        bad, n = ctx.selftest_fastmath(2048, 512)
+    assert n == 2048 * 256 * 512 and bad == [0, 0, 0, 0], bad
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "pbc2d_n16", "trap3d_n8"])
+def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
+    d = load_golden(name)
+    cfg, S = config_from_golden(d), system_from_golden(d)
+    VT, WF = _tables(d)
+    n = len(d["ip"])
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
+        ctx.set_tuning("k1_variant", variant)
+        ctx.upload(0, d["Path"])
+        dS = ctx.delta_action_batch(np.zeros(n, np.int32), d["ip"], d["ib"], d["xnew"], d["xold"])
+    ref = d["DeltaS"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(dS), np.isnan(ref))
+    sv, sf, su = term_scales(S, VT, WF, d["Path"], d["ip"], d["ib"], d["xnew"], d["xold"])
+    tol = delta_s_tolerance(S, sv, sf, su)
+    assert np.all(np.abs(dS - ref)[fin] <= tol[fin])
+    u = np.random.default_rng(1).uniform(size=n)
+    with np.errstate(over="ignore", invalid="ignore"):
+        assert np.array_equal(np.exp(-dS) >= u, np.exp(-ref) >= u)
+
+
 def _random_batch(rng, S, Paths, n, sigma):
     W = Paths.shape[0]
     w = rng.integers(0, W, n).astype(np.int32)
