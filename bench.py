@@ -189,6 +189,16 @@ def main():
     value = world * pair_evals_per_step * args.steps / elapsed
     alg_bytes = n_items * (cfg.dim * cfg.Np * 8 + 2 * cfg.dim * 8 + 8)      # 6 200 B/item
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, gfx950 FETCH_SIZE x2 correction: profiles/README.md) -- valid for this workload only
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("algorithmic_bytes_per_launch") == alg_bytes:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     # correctness of what was timed: rank 0 checks one stage against the oracle
     got = d_out[0].cpu().numpy()
@@ -217,8 +227,8 @@ def main():
                        "walkers_per_gpu": W, "items_per_step": n_items,
                        "stages_per_sweep_equiv": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_delta_action<3,false>", "kernel_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "pigs::k_delta_action_v2<3,false,false,false,256>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),

@@ -1,0 +1,150 @@
+/* pigs_cpu_shim.c -- TEST INFRASTRUCTURE ONLY (lives under tests/, never shipped, never
+ * loaded by the product).  Implements the C ABI of include/pigs_hip.h on the CPU with the
+ * pinned oracle (oracle/pigs_oracle.c) so that the HOST LOGIC of the Fortran sampler
+ * (RNG streams, proposal generation, accept/reject bookkeeping, output files) can be
+ * tested in a container without a GPU against runs of the reference program.
+ * It is not a fallback: the product library libpigs_hip.so has no CPU path, and nothing
+ * outside tests/ links this file.  Parity claims for the kernels never rest on it.      */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/pigs_hip.h"
+#include "../../oracle/pigs_oracle.h"
+
+struct pigs_ctx {
+    po_sys  s;
+    double  dt;
+    int     W;
+    size_t  wl;        /* doubles per worldline */
+    double *VT, *WF, *paths;
+};
+
+static char g_err[256] = "";
+const char *pigs_last_error(void) { return g_err; }
+int pigs_abi_version(void) { return PIGS_ABI_VERSION; }
+int pigs_device_count(int32_t *n) { *n = 1; return PIGS_OK; }
+int pigs_sync(pigs_ctx *c) { (void)c; return PIGS_OK; }
+int pigs_stream(pigs_ctx *c, void **s) { (void)c; *s = NULL; return PIGS_OK; }
+int pigs_set_tuning(pigs_ctx *c, const char *k, int32_t v) { (void)c; (void)k; (void)v; return PIGS_OK; }
+
+int pigs_ctx_create(const pigs_params *p, const double *VT, const double *WF, int32_t W, int32_t dev, pigs_ctx **out)
+{
+    (void)dev;
+    pigs_ctx *c = calloc(1, sizeof *c);
+    c->s.dim = p->dim; c->s.Np = p->Np; c->s.Nb = p->Nb; c->s.Nmax = p->Nmax;
+    c->s.trap = p->trap; c->s.wf_table = p->wf_table; c->s.v_table = p->v_table;
+    c->s.dr = p->dr; c->s.rcut2 = p->rcut2; c->s.Rm = p->Rm;
+    for (int k = 0; k < 3; ++k) {
+        c->s.Lbox[k] = k < p->dim ? p->Lbox[k] : 1.0;
+        c->s.LboxHalf[k] = 0.5 * c->s.Lbox[k];
+        c->s.a_ho[k] = k < p->dim ? p->a_ho[k] : 1.0;
+    }
+    c->dt = p->dt; c->W = W;
+    c->wl = (size_t)p->dim * p->Np * (2 * (size_t)p->Nb + 1);
+    size_t tb = (size_t)(p->Nmax + 2) * sizeof(double);
+    c->VT = malloc(tb); c->WF = malloc(tb);
+    memcpy(c->VT, VT, tb); memcpy(c->WF, WF, tb);
+    c->paths = calloc(c->wl * W, sizeof(double));
+    *out = c;
+    return PIGS_OK;
+}
+
+int pigs_ctx_destroy(pigs_ctx *c)
+{
+    if (!c) return PIGS_OK;
+    free(c->VT); free(c->WF); free(c->paths); free(c);
+    return PIGS_OK;
+}
+
+int pigs_build_tables(int32_t Nmax, double Rm, double rmax, double *VT, double *WF, double *dr)
+{
+    if (VT) po_potential_table(Nmax, rmax, VT);
+    if (WF) po_jastrow_table(Nmax, Rm, rmax, WF);
+    if (dr) *dr = po_table_dr(rmax, Nmax);
+    return PIGS_OK;
+}
+
+int pigs_path_upload(pigs_ctx *c, int32_t w, const double *P) { memcpy(c->paths + c->wl * w, P, c->wl * sizeof(double)); return PIGS_OK; }
+int pigs_path_download(pigs_ctx *c, int32_t w, double *P) { memcpy(P, c->paths + c->wl * w, c->wl * sizeof(double)); return PIGS_OK; }
+int pigs_path_upload_all(pigs_ctx *c, const double *P) { memcpy(c->paths, P, c->wl * c->W * sizeof(double)); return PIGS_OK; }
+int pigs_path_download_all(pigs_ctx *c, double *P) { memcpy(P, c->paths, c->wl * c->W * sizeof(double)); return PIGS_OK; }
+
+int pigs_delta_action_batch(pigs_ctx *c, int64_t n, const int32_t *w, const int32_t *ip, const int32_t *ib,
+                            const double *xn, const double *xo, double *dS)
+{
+    po_delta_action_batch(&c->s, c->WF, c->VT, c->paths, n, w, ip, ib, xn, xo, c->dt, dS);
+    return PIGS_OK;
+}
+
+int pigs_delta_action_batch_dev(pigs_ctx *c, int64_t n, const int32_t *w, const int32_t *ip, const int32_t *ib,
+                                const double *xn, const double *xo, double *dS)
+{
+    return pigs_delta_action_batch(c, n, w, ip, ib, xn, xo, dS);
+}
+
+int pigs_delta_action_parts(pigs_ctx *c, int64_t n, const int32_t *w, const int32_t *ip, const int32_t *ib,
+                            const double *xn, const double *xo, double *parts)
+{
+    const int d = c->s.dim;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *R = c->paths + c->wl * w[i] + (size_t)ib[i] * d * c->s.Np;
+        double dp, df = 0.0, dw = 0.0;
+        if (ib[i] % 2) po_update_pot(&c->s, c->VT, ip[i], R, xn + i * d, xo + i * d, &dp, &df);
+        else po_update_pot(&c->s, c->VT, ip[i], R, xn + i * d, xo + i * d, &dp, NULL);
+        if (ib[i] == 0 || ib[i] == 2 * c->s.Nb) po_update_wf(&c->s, c->WF, ip[i], R, xn + i * d, xo + i * d, &dw);
+        parts[3 * i] = dp; parts[3 * i + 1] = df; parts[3 * i + 2] = dw;
+    }
+    return PIGS_OK;
+}
+
+int pigs_commit_beads(pigs_ctx *c, int64_t n, const int32_t *w, const int32_t *ip, const int32_t *ib, const double *x)
+{
+    const int d = c->s.dim;
+    for (int64_t i = 0; i < n; ++i)
+        memcpy(c->paths + c->wl * w[i] + ((size_t)ib[i] * c->s.Np + (ip[i] - 1)) * d, x + i * d, d * sizeof(double));
+    return PIGS_OK;
+}
+
+int pigs_swap_tails(pigs_ctx *c, int32_t w, int32_t iw, int32_t ik)
+{
+    const int d = c->s.dim;
+    for (int ib = c->s.Nb; ib <= 2 * c->s.Nb; ++ib)
+        for (int k = 0; k < d; ++k) {
+            double *a = c->paths + c->wl * w + ((size_t)ib * c->s.Np + (iw - 1)) * d + k;
+            double *b = c->paths + c->wl * w + ((size_t)ib * c->s.Np + (ik - 1)) * d + k;
+            double t = *a; *a = *b; *b = t;
+        }
+    return PIGS_OK;
+}
+
+int pigs_potential_energy_slice(pigs_ctx *c, int32_t w, int32_t ib, int32_t want, double *Pot, double *F2)
+{
+    const double *R = c->paths + c->wl * w + (size_t)ib * c->s.dim * c->s.Np;
+    po_potential_energy(&c->s, c->VT, R, Pot, want ? F2 : NULL);
+    if (!want && F2) *F2 = 0.0;
+    return PIGS_OK;
+}
+
+int pigs_therm_energy_batch(pigs_ctx *c, int32_t n, const int32_t *ws, double *E, double *Ec, double *Ep)
+{
+    for (int i = 0; i < n; ++i)
+        po_therm_energy(&c->s, c->VT, c->paths + c->wl * (ws ? ws[i] : i), c->dt, &E[i], &Ec[i], &Ep[i]);
+    return PIGS_OK;
+}
+
+int pigs_local_energy_batch(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t ib, double *E, double *K, double *P)
+{
+    for (int i = 0; i < n; ++i)
+        po_local_energy(&c->s, c->WF, c->VT, c->paths + c->wl * (ws ? ws[i] : i) + (size_t)ib * c->s.dim * c->s.Np,
+                        &E[i], &K[i], &P[i]);
+    return PIGS_OK;
+}
+
+int pigs_comm_unique_id(char id[128]) { memset(id, 0, 128); return PIGS_OK; }
+int pigs_comm_init_rank(pigs_ctx *c, int32_t n, int32_t r, const char id[128]) { (void)c; (void)n; (void)r; (void)id; return PIGS_OK; }
+int pigs_comm_init_all(pigs_ctx **c, int32_t n) { (void)c; (void)n; return PIGS_OK; }
+int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n) { (void)c; (void)v; (void)n; return PIGS_OK; }
+int pigs_selftest_fastmath(pigs_ctx *c, int32_t b, int32_t i, uint64_t bad[4]) { (void)c; (void)b; (void)i; memset(bad, 0, 32); return PIGS_OK; }
