@@ -1,0 +1,442 @@
+!-----------------------------------------------------------------------
+! pigs_vpi -- the vpi.in-driven front end on MI355X.
+!
+!   pigs_vpi < vpi.in
+!
+! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
+! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
+! system_mod.f90:15-34) plus one optional group of its own,
+!     &gpu  n_walkers = 1, device = 0  /
+! runs n_walkers independent PIGS chains in lock-step (walker w uses seed+w-1, so walker 1
+! IS the reference's chain), every Delta S / energy sum on the GPU through libpigs_hip.so,
+! and writes the reference's observable files: e_vpi.out, et_vpi.out ('(5g20.10e3)'),
+! gr_vpi.out, sk_vpi.out, nr_vpi.out ('(20g20.10e3)'), fort.99-style permutation histogram
+! (perm_vpi.out), plus e_vpi.hex / et_vpi.hex with the same numbers as 64-bit hex for
+! parity checks beyond 10 digits.  With n_walkers > 1 the per-walker files carry a .wNNNN
+! suffix and the unsuffixed files hold the walker average.
+! The step / block structure follows reference vpi.f90:244-588.
+!-----------------------------------------------------------------------
+program pigs_vpi
+
+  use iso_c_binding
+  use pigs_capi
+  use pigs_rng
+  use pigs_sampler
+  use pigs_estimators
+
+  implicit none
+
+  ! ---- namelist variables (names fixed by the input format)
+  logical           :: crystal,trap,resume,swapping,wf_table,v_table
+  character (len=3) :: sampling
+  real (kind=8)     :: density,dt,delta_cm,CWorm,Rm
+  real (kind=8)     :: a_ho(3)
+  integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
+  integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios
+  namelist /system/  dim,Np,density,crystal,trap
+  namelist /samp/    resume,dt,Nb,seed,delta_cm,CMFreq,sampling,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
+  namelist /obdm/    swapping,CWorm,Nobdm,Npw
+  namelist /wavefun/ Nmax,wf_table,v_table
+  namelist /extpot/  a_ho
+  namelist /jastrow/ Rm
+  namelist /gpu/     n_walkers,device
+
+  type(sampler_t)    :: s
+  type(est_params)   :: ep
+  type(pigs_params)  :: gp
+  type(c_ptr)        :: ctx
+  type(perm_state), allocatable :: perm(:)
+
+  real(8) :: Lbox(3),rcut,rcut2,rbin,dr,pi
+  real(8), allocatable :: VTable(:),LogWF(:)
+  integer :: NW,w,k,ip,ib,istep,iblock,istag,iobdm,j,nd,i
+  integer, allocatable :: ipv(:),iupd(:),partner(:),diag_list(:)
+  logical, allocatable :: act(:),isopen0(:),swp(:)
+  integer(c_int32_t), allocatable :: wl(:)
+  real(8), allocatable :: E1(:),E2(:),K1(:),P1(:),Et(:),Kt(:),Pt(:)
+  real(8) :: E,Kin,Pot
+
+  ! per-walker counters and accumulators (one column per walker)
+  integer, allocatable :: acc_cm(:),acc_bd(:),acc_head(:),acc_tail(:),acc_cm_half(:),acc_bd_half(:)
+  integer, allocatable :: acc_head_half(:),acc_tail_half(:),acc_open(:),acc_close(:),acc_swap(:)
+  integer, allocatable :: try_open(:),try_close(:),try_swap(:)
+  real(8), allocatable :: try_cm(:),try_stag(:),try_cm_half(:),try_stag_half(:)
+  integer, allocatable :: idiag(:),idiag_aux(:),idiag_block(:),obdm_bl(:),diag_bl(:),ngr(:)
+  real(8), allocatable :: BE(:,:),BE2(:,:),BT(:,:),BT2(:,:),AE(:,:),AE2(:,:),AT(:,:),AT2(:,:)
+  real(8), allocatable :: gr(:,:),AvGr(:,:),AvGr2(:,:),Sk(:,:,:),AvSk(:,:,:),AvSk2(:,:,:)
+  real(8), allocatable :: nrho(:,:,:),AvNr(:,:,:),AvNr2(:,:,:)
+  real(8) :: t0,t1,mE(3),mT(3)
+  integer, allocatable :: ue(:),ut(:),uh(:)
+  integer :: ueav,utav
+  character(len=32) :: suffix
+
+  !---------------------------------------------------------------------
+  ! defaults (reference vpi_mod.f90:39-60) and input
+  crystal = .false.; trap = .false.
+  resume = .false.; seed = 1982; Lstag = 2; Nlev = 1
+  swapping = .false.; CWorm = 0.d0; Nobdm = 0; Npw = 0
+  Nmax = 10000; wf_table = .false.; v_table = .false.
+  CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
+  delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
+  n_walkers = 1; device = 0
+
+  read (5,nml=system,iostat=ios);  rewind (5)
+  read (5,nml=samp,iostat=ios);    rewind (5)
+  read (5,nml=obdm,iostat=ios);    rewind (5)
+  read (5,nml=wavefun,iostat=ios); rewind (5)
+  if (trap) then
+     read (5,nml=extpot,iostat=ios); rewind (5)
+  end if
+  read (5,nml=jastrow,iostat=ios); rewind (5)
+  read (5,nml=gpu,iostat=ios);     rewind (5)
+
+  if (crystal .or. resume) then
+     write (0,*) 'pigs_vpi: crystal / resume start-up is not supported yet'
+     stop 2
+  end if
+  if (.not. (wf_table .and. v_table)) then
+     write (0,*) 'pigs_vpi: wf_table = T and v_table = T are required (the reference Force() is a stub)'
+     stop 2
+  end if
+  NW  = n_walkers
+  pi = acos(-1.d0)
+
+  ! box, cutoff, grids (reference vpi.f90:82-128)
+  Lbox = 1.d0
+  if (trap) then
+     rcut = 1.d0
+     do k=1,dim
+        rcut = 3.d0*rcut*a_ho(k)
+     end do
+     density  = real(Np)/(pi**(0.5d0*dim)*rcut/gamma(0.5d0*dim+1.d0))
+     rcut     = rcut**(1.d0/real(dim))
+     rcut     = 10.d0*rcut
+     delta_cm = delta_cm*minval(a_ho(1:dim))
+  else
+     do k=1,dim
+        Lbox(k) = (real(Np)/density)**(1.d0/real(dim))
+     end do
+     rcut     = minval(0.5d0*Lbox(1:dim))
+     delta_cm = delta_cm/density**(1.d0/real(dim))
+  end if
+  rcut2 = rcut*rcut
+  rbin  = rcut/real(Nbin)
+
+  ! tables on the host (reference vpi_mod.f90:84-145), then the GPU context
+  allocate (VTable(0:Nmax+1),LogWF(0:Nmax+1))
+  call pigs_check(pigs_build_tables(int(Nmax,c_int32_t),Rm,rcut,VTable,LogWF,dr),'pigs_build_tables')
+  gp%dim = dim; gp%Np = Np; gp%Nb = Nb; gp%Nmax = Nmax
+  gp%trap = merge(1,0,trap); gp%wf_table = 1; gp%v_table = 1; gp%reserved = 0
+  gp%dr = dr; gp%rcut2 = rcut2; gp%dt = dt; gp%Rm = Rm
+  gp%Lbox = Lbox; gp%a_ho = a_ho
+  call pigs_check(pigs_ctx_create(gp,VTable,LogWF,int(NW,c_int32_t),int(device,c_int32_t),ctx),'pigs_ctx_create')
+
+  call sampler_init(s,dim,Np,Nb,NW,trap,dt,density,CWorm,Lbox(1:dim),ctx)
+  ep%dim = dim; ep%Np = Np; ep%Nbin = Nbin; ep%Nk = Nk; ep%Npw = Npw; ep%trap = trap
+  ep%rcut2 = rcut2; ep%rbin = rbin; ep%pi = pi; ep%CWorm = CWorm
+  ep%Lbox = Lbox; ep%LboxHalf = 0.5d0*Lbox; ep%qbin = 2.d0*pi/Lbox
+
+  ! initial configuration (reference vpi_mod.f90:189-254): uniform random positions, every
+  ! bead of a particle at the same point; walker w seeds its stream with seed+w-1
+  do w=1,NW
+     call mt_seed(s%rng(w),seed+w-1)
+     do ip=1,Np
+        do k=1,dim
+           if (trap) then
+              s%Path(k,ip,0,w) = 2.d0*a_ho(k)*(mt_real(s%rng(w))-0.5d0)
+           else
+              s%Path(k,ip,0,w) = Lbox(k)*(mt_real(s%rng(w))-0.5d0)
+           end if
+        end do
+     end do
+     do ib=1,2*Nb
+        s%Path(:,:,ib,w) = s%Path(:,:,0,w)
+     end do
+     s%xend(:,1,w) = s%Path(:,Np,Nb,w)
+     s%xend(:,2,w) = s%xend(:,1,w)
+  end do
+  call sampler_upload(s)
+
+  allocate (perm(NW))
+  do w=1,NW
+     allocate (perm(w)%members(Np),perm(w)%histogram(Np))
+     perm(w)%members = 0; perm(w)%histogram = 0
+  end do
+
+  allocate (ipv(NW),iupd(NW),partner(NW),diag_list(NW),act(NW),isopen0(NW),swp(NW),wl(NW))
+  allocate (E1(NW),E2(NW),K1(NW),P1(NW),Et(NW),Kt(NW),Pt(NW))
+  allocate (acc_cm(NW),acc_bd(NW),acc_head(NW),acc_tail(NW),acc_cm_half(NW),acc_bd_half(NW))
+  allocate (acc_head_half(NW),acc_tail_half(NW),acc_open(NW),acc_close(NW),acc_swap(NW))
+  allocate (try_open(NW),try_close(NW),try_swap(NW),try_cm(NW),try_stag(NW),try_cm_half(NW),try_stag_half(NW))
+  allocate (idiag(NW),idiag_aux(NW),idiag_block(NW),obdm_bl(NW),diag_bl(NW),ngr(NW))
+  allocate (BE(3,NW),BE2(3,NW),BT(3,NW),BT2(3,NW),AE(3,NW),AE2(3,NW),AT(3,NW),AT2(3,NW))
+  allocate (gr(Nbin,NW),AvGr(Nbin,NW),AvGr2(Nbin,NW),Sk(dim,Nk,NW),AvSk(dim,Nk,NW),AvSk2(dim,Nk,NW))
+  allocate (nrho(0:Npw,Nbin,NW),AvNr(0:Npw,Nbin,NW),AvNr2(0:Npw,Nbin,NW))
+  AE = 0.d0; AE2 = 0.d0; AT = 0.d0; AT2 = 0.d0
+  AvGr = 0.d0; AvGr2 = 0.d0; AvSk = 0.d0; AvSk2 = 0.d0; AvNr = 0.d0; AvNr2 = 0.d0; nrho = 0.d0
+  idiag = 0; idiag_aux = 0; obdm_bl = 0; diag_bl = 0
+
+  allocate (ue(NW),ut(NW),uh(NW))
+  do w=1,NW
+     suffix = ''
+     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     open (newunit=ue(w),file='e_vpi'//trim(suffix)//'.out')
+     open (newunit=ut(w),file='et_vpi'//trim(suffix)//'.out')
+     open (newunit=uh(w),file='e_vpi'//trim(suffix)//'.hex')
+  end do
+  if (NW>1) then
+     open (newunit=ueav,file='e_vpi.out')
+     open (newunit=utav,file='et_vpi.out')
+  end if
+
+  print '(a)',       ' =============================================================='
+  print '(a)',       '            VPI Monte Carlo on MI355X (pigs_vpi)               '
+  print '(a)',       ' =============================================================='
+  print '(a,i6)',    '  > Walkers (lock-step) :',NW
+  print '(a,i6)',    '  > Dimensions          :',dim
+  print '(a,i6)',    '  > Number of particles :',Np
+  print '(a,i6)',    '  > Number of beads     :',Nb
+  print '(a,g13.6)', '  > Time step           :',dt
+  print '(a,i6)',    '  > Number of blocks    :',Nblock
+  print '(a,i6)',    '  > MC steps per block  :',Nstep
+
+  !=====================================================================
+  do iblock=1,Nblock
+
+     call cpu_time(t0)
+     try_open = 0; acc_open = 0; try_close = 0; acc_close = 0
+     try_cm = 0; acc_cm = 0; try_stag = 0; acc_bd = 0; acc_head = 0; acc_tail = 0
+     try_cm_half = 0; acc_cm_half = 0; try_stag_half = 0
+     acc_bd_half = 0; acc_head_half = 0; acc_tail_half = 0
+     try_swap = 0; acc_swap = 0
+     idiag_block = 0; ngr = 0; gr = 0.d0; Sk = 0.d0
+     BE = 0.d0; BE2 = 0.d0; BT = 0.d0; BT2 = 0.d0
+
+     do istep=1,Nstep
+
+        ! ---- open / close attempt (reference vpi.f90:302-323)
+        isopen0 = s%isopen
+        do w=1,NW
+           iupd(w) = int(mt_real(s%rng(w))*2)
+        end do
+        act = isopen0 .and. iupd==0
+        if (any(act)) then
+           call mv_close(s,Lstag,act,acc_close)
+           do w=1,NW
+              if (.not. act(w)) cycle
+              perm(w)%end_cycle = .not. s%isopen(w)
+              try_close(w) = try_close(w)+1
+              if (swapping) call perm_sampling(perm(w),s%isopen(w),s%iworm(w))
+           end do
+        end if
+        act = (.not. isopen0) .and. iupd==1
+        if (any(act)) then
+           do w=1,NW
+              if (act(w)) s%iworm(w) = min(int(mt_real(s%rng(w))*Np)+1,Np)
+           end do
+           call mv_open(s,Lstag,s%iworm,act,acc_open)
+           do w=1,NW
+              if (.not. act(w)) cycle
+              perm(w)%new_cycle = s%isopen(w)
+              try_open(w) = try_open(w)+1
+              if (swapping) call perm_sampling(perm(w),s%isopen(w),s%iworm(w))
+           end do
+        end if
+
+        ! ---- centre-of-mass and bead moves of every (non-worm) particle
+        if (mod(istep,CMFreq)==0) then
+           do ip=1,Np
+              ipv = ip
+              act = .not. (s%isopen .and. s%iworm==ip)
+              where (act) try_cm = try_cm+1
+              call mv_translate(s,delta_cm,ipv,act,acc_cm)
+           end do
+        end if
+        do istag=1,Nstag
+           do ip=1,Np
+              ipv = ip
+              act = .not. (s%isopen .and. s%iworm==ip)
+              where (act) try_stag = try_stag+1
+              if (sampling=="sta") then
+                 call mv_end_staging(s,HEAD,Lstag,ipv,act,acc_head)
+                 call mv_end_staging(s,TAIL,Lstag,ipv,act,acc_tail)
+                 call mv_staging(s,Lstag,ipv,act,acc_bd)
+              else
+                 call mv_end_bisection(s,HEAD,Nlev,ipv,act,acc_head)
+                 call mv_end_bisection(s,TAIL,Nlev,ipv,act,acc_tail)
+                 call mv_bisection(s,Nlev,ipv,act,acc_bd)
+              end if
+           end do
+        end do
+
+        ! ---- worm moves of the walkers in the off-diagonal sector (reference vpi.f90:370-404)
+        act = s%isopen
+        if (any(act)) then
+           do iobdm=1,Nobdm
+              do j=1,2
+                 where (act) try_cm_half = try_cm_half+1
+                 call mv_translate_half(s,j,delta_cm,act,acc_cm_half)
+              end do
+              do j=1,2
+                 where (act) try_stag_half = try_stag_half+1
+                 call mv_end_staging_half(s,HEAD,j,Lstag,act,acc_head_half)
+                 call mv_end_staging_half(s,TAIL,j,Lstag,act,acc_tail_half)
+                 call mv_staging_half(s,j,Lstag,act,acc_bd_half)
+              end do
+              if (swapping) then
+                 where (act) try_swap = try_swap+1
+                 call mv_swap(s,Lstag,act,acc_swap,partner,swp)
+                 do w=1,NW
+                    if (act(w)) call perm_sampling(perm(w),s%isopen(w),s%iworm(w),partner(w),swp(w))
+                 end do
+              end if
+              if (.not. trap) then
+                 do w=1,NW
+                    if (act(w)) call obdm_accumulate(ep,s%xend(:,:,w),nrho(:,:,w))
+                 end do
+              end if
+           end do
+        end if
+
+        ! ---- estimators of the walkers in the diagonal sector (reference vpi.f90:406-473)
+        nd = 0
+        do w=1,NW
+           if (.not. s%isopen(w)) then
+              nd = nd+1
+              diag_list(nd) = w
+              wl(nd) = w-1
+           end if
+        end do
+        if (nd>0) then
+           call sampler_flush(s)
+           call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,0_c_int32_t,E1,K1,P1),'pigs_local_energy_batch')
+           call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,int(2*Nb,c_int32_t),E2,K1,P1), &
+                & 'pigs_local_energy_batch')
+           call pigs_check(pigs_therm_energy_batch(ctx,int(nd,c_int32_t),wl,Et,Kt,Pt),'pigs_therm_energy_batch')
+           do i=1,nd
+              w = diag_list(i)
+              idiag(w) = idiag(w)+1; idiag_aux(w) = idiag_aux(w)+1; idiag_block(w) = idiag_block(w)+1
+              E   = 0.5d0*(E1(i)+E2(i))
+              Pot = Pt(i)
+              Kin = E-Pot
+              BE(:,w)  = BE(:,w)+[E,Kin,Pot]
+              BT(:,w)  = BT(:,w)+[Et(i),Kt(i),Pot]
+              BE2(:,w) = BE2(:,w)+[E**2,Kin**2,Pot**2]
+              BT2(:,w) = BT2(:,w)+[Et(i)**2,Kt(i)**2,Pot**2]
+              ngr(w) = ngr(w)+1
+              if (.not. trap) then
+                 call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
+                 call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
+              end if
+           end do
+        end if
+
+     end do   ! istep
+
+     ! ---- end of block (reference vpi.f90:477-545)
+     mE = 0.d0; mT = 0.d0; nd = 0
+     do w=1,NW
+        if (idiag_block(w)/=0) then
+           BE(:,w)  = BE(:,w)/real(idiag_block(w));  BE2(:,w) = BE2(:,w)/real(idiag_block(w))
+           BT(:,w)  = BT(:,w)/real(idiag_block(w));  BT2(:,w) = BT2(:,w)/real(idiag_block(w))
+           diag_bl(w) = diag_bl(w)+1
+           AE(:,w)  = AE(:,w)+BE(:,w);  AE2(:,w) = AE2(:,w)+BE(:,w)**2
+           AT(:,w)  = AT(:,w)+BT(:,w);  AT2(:,w) = AT2(:,w)+BT(:,w)**2
+           if (.not. trap) then
+              call normalize_gr(ep,density,ngr(w),gr(:,w))
+              call normalize_sk(ep,ngr(w),Sk(:,:,w))
+              AvGr(:,w) = AvGr(:,w)+gr(:,w); AvGr2(:,w) = AvGr2(:,w)+gr(:,w)*gr(:,w)
+              AvSk(:,:,w) = AvSk(:,:,w)+Sk(:,:,w); AvSk2(:,:,w) = AvSk2(:,:,w)+Sk(:,:,w)*Sk(:,:,w)
+           end if
+           write (ue(w),'(5g20.10e3)') real(iblock),BE(1,w)/Np,BE(2,w)/Np,BE(3,w)/Np
+           write (ut(w),'(5g20.10e3)') real(iblock),BT(1,w)/Np,BT(2,w)/Np,BT(3,w)/Np
+           write (uh(w),'(i8,6(1x,z16.16))') iblock,BE(1,w)/Np,BE(2,w)/Np,BE(3,w)/Np,BT(1,w)/Np,BT(2,w)/Np,BT(3,w)/Np
+           mE = mE+BE(:,w)/Np; mT = mT+BT(:,w)/Np; nd = nd+1
+        end if
+        if (idiag_aux(w)/Nstep>=1) then
+           obdm_bl(w) = obdm_bl(w)+1
+           if (.not. trap) then
+              call normalize_nr(ep,density,real(idiag_aux(w),8),Nobdm,nrho(:,:,w))
+              AvNr(:,:,w) = AvNr(:,:,w)+nrho(:,:,w); AvNr2(:,:,w) = AvNr2(:,:,w)+nrho(:,:,w)*nrho(:,:,w)
+           end if
+           idiag_aux(w) = 0
+           nrho(:,:,w)  = 0.d0
+        end if
+     end do
+     if (NW>1 .and. nd>0) then
+        write (ueav,'(5g20.10e3)') real(iblock),mE/nd
+        write (utav,'(5g20.10e3)') real(iblock),mT/nd
+     end if
+     call cpu_time(t1)
+
+     print '(a)',            ' -----------------------------------------------------------'
+     print '(a,i8)',         ' BLOCK NUMBER :',iblock
+     if (nd>0) then
+        print '(a,3g18.9)',  '   > <E>,<Ec>,<Ep>  =',mE/nd
+        print '(a,3g18.9)',  '   > <Et>,<Kt>,<Vt> =',mT/nd
+     end if
+     print '(a,f7.2,a)',     '   > CM movements      =',100*real(sum(acc_cm))/max(sum(try_cm),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Staging movements =',100*real(sum(acc_bd))/max(sum(try_stag),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Head movements    =',100*real(sum(acc_head))/max(sum(try_stag),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Tail movements    =',100*real(sum(acc_tail))/max(sum(try_stag),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Diagonal conf.    =',100.d0*real(sum(idiag_block))/real(Nstep*NW),' %'
+     print '(a,f7.2,a)',     '   > Open acc          =',100.d0*real(sum(acc_open))/max(real(sum(try_open)),1.0),' %'
+     print '(a,f7.2,a)',     '   > Close acc         =',100.d0*real(sum(acc_close))/max(real(sum(try_close)),1.0),' %'
+     print '(a,f7.2,a)',     '   > Swap acc          =',100.d0*real(sum(acc_swap))/max(real(sum(try_swap)),1.0),' %'
+     print '(a,f9.2,a,i12,a,i10,a)', '   > Time per block    =',t1-t0,' s;  Delta S items so far',s%n_eval_items, &
+          & ' in',s%n_eval_calls,' batches'
+
+  end do   ! iblock
+
+  !=====================================================================
+  ! final averages and files (reference vpi.f90:590-642)
+  do w=1,NW
+     suffix = ''
+     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     close (ue(w)); close (ut(w)); close (uh(w))
+     if (swapping) then
+        open (newunit=k,file='perm_vpi'//trim(suffix)//'.out')
+        do ip=1,Np
+           write (k,*) ip,perm(w)%histogram(ip)
+        end do
+        close (k)
+     end if
+     if (.not. trap) then
+        if (diag_bl(w)>0) then
+           call write_radial('gr_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvGr(:,w),AvGr2(:,w))
+           call write_sk('sk_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvSk(:,:,w),AvSk2(:,:,w))
+        end if
+        if (obdm_bl(w)>0) call write_nr('nr_vpi'//trim(suffix)//'.out',ep,obdm_bl(w),AvNr(:,:,w),AvNr2(:,:,w))
+     end if
+  end do
+  if (NW>1) then
+     close (ueav); close (utav)
+  end if
+
+  print '(a)', ' =============================================================='
+  print '(a)', ' FINAL RESULTS (per walker: <E> <Ec> <Ep> | <Et> <Kt> <Vt>, per particle)'
+  do w=1,NW
+     if (diag_bl(w)>0) print '(i6,6g16.8)', w-1,AE(:,w)/real(diag_bl(w))/Np,AT(:,w)/real(diag_bl(w))/Np
+  end do
+  print '(a)', ' =============================================================='
+
+  ! final worldlines back from the device must equal the host mirror: the two were kept in
+  ! step by commits only
+  call sampler_flush(s)
+  block
+    real(8), allocatable :: chk(:,:,:,:)
+    allocate (chk(dim,Np,0:2*Nb,NW))
+    call pigs_check(pigs_path_download_all(ctx,chk),'pigs_path_download_all')
+    if (any(chk/=s%Path)) then
+       write (0,*) 'pigs_vpi: device worldlines differ from the host mirror'
+       stop 3
+    end if
+    open (newunit=k,file='worldlines_final.bin',form='unformatted',access='stream')
+    write (k) chk
+    close (k)
+  end block
+
+  call sampler_free(s)
+  call pigs_check(pigs_ctx_destroy(ctx),'pigs_ctx_destroy')
+
+end program pigs_vpi

@@ -184,3 +184,47 @@ def ref_gf(ref, S, opt, ib):
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# End-to-end runs of the stock reference PROGRAM (oracle/_ref/vpi): its output files are kept
+# as data fixtures under tests/golden/vpi_runs/<name>/ for the front-end / sampler tests.
+RUNS = {
+    # worm sector active: open / close / swap / OBDM, bisection sampling
+    "he4_worm_s1982": dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                           Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
+    "he4_worm_s1983": dict(dim=3, Np=16, Nb=8, seed=1983, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                           Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
+    "he4_worm_s1984": dict(dim=3, Np=16, Nb=8, seed=1984, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                           Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
+    # BASELINE config 1: 1D harmonic oscillator, N=2, 21 beads, staging sampling (swapping=T: quirk Q9)
+    "ho1d_n2": dict(dim=1, Np=2, Nb=10, seed=1982, trap="T", a_ho="1.0d0", sampling="sta", Lstag=6, Nlev=2,
+                    Nstag=4, Nblock=5, Nstep=40, CWorm="0.3d0", Nobdm=2, Npw=0, dt="1.0d-2"),
+    # stock vpi.in (N=64, 65 beads, bis, Nlev=4, Nstag=5, worm on), shortened
+    "he4_stock_short": dict(dim=3, Np=64, Nb=32, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                            Nblock=2, Nstep=6, CWorm="0.5d0", Nobdm=10, Npw=0),
+    # CWorm = 0 (quirk Q11): an open proposal is generated and always rejected
+    "he4_cworm0": dict(dim=2, Np=9, Nb=6, seed=7, density="0.25d0", sampling="sta", Lstag=4, Nlev=2, Nstag=2,
+                       Nblock=3, Nstep=20, CWorm="0.0d0", Nobdm=0, Npw=0),
+}
+RUN_FILES = ["e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out", "fort.99"]
+
+
+def make_runs():
+    import shutil
+    base = os.path.join(OUT, "vpi_runs")
+    for name, kw in RUNS.items():
+        dst = os.path.join(base, name)
+        os.makedirs(dst, exist_ok=True)
+        with tempfile.TemporaryDirectory() as td:
+            P = run_vpi(td, **kw)
+            shutil.copy(os.path.join(td, "vpi.in"), os.path.join(dst, "vpi.in"))
+            for f in RUN_FILES:
+                if os.path.exists(os.path.join(td, f)):
+                    shutil.copy(os.path.join(td, f), os.path.join(dst, f))
+            np.savez_compressed(os.path.join(dst, "final_worldline.npz"), Path=P)
+    print("reference program runs written to", base)
+
+
+if __name__ == "__main__":
+    make_runs()

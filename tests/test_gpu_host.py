@@ -1,0 +1,68 @@
+"""End-to-end on the MI355X: the Fortran front end (host/pigs_vpi, linked against libpigs_hip.so)
+against the output files of the reference PROGRAM (tests/golden/vpi_runs).
+
+Identical-seed parity (BASELINE.json north star): the worldline depends only on the random
+stream and the accept/reject decisions, so with identical decisions the FINAL WORLDLINE IS
+BIT-IDENTICAL to the reference's although every Delta S was summed in a different order on the GPU;
+block energies (E, K, V, Et, Kt, Vt per particle) agree to 1e-10 relative."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from helpers import same_bits
+
+pytestmark = pytest.mark.gpu
+RUNS = os.path.join(GOLDEN, "vpi_runs")
+HOST = os.path.join(ROOT, "pathintegralgroundstate_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def exe(gpu_lib):
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return os.path.join(HOST, "pigs_vpi")
+
+
+def _run(exe, txt, wd):
+    with open(os.path.join(wd, "vpi.in"), "w") as f:
+        f.write(txt)
+    with open(os.path.join(wd, "vpi.in")) as fin, open(os.path.join(wd, "stdout.txt"), "w") as fo:
+        r = subprocess.run([exe], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=wd, timeout=900)
+    assert r.returncode == 0, open(os.path.join(wd, "stdout.txt")).read()[-3000:]
+
+
+def _close(mine, ref, rel=1e-10):
+    a, b = np.atleast_2d(np.loadtxt(mine)), np.atleast_2d(np.loadtxt(ref))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    # files carry 10 significant digits: allow one unit in the last printed place on top of rel
+    return np.all(np.abs(a - b) <= rel * np.abs(b) + 1.01e-9 * np.abs(b))
+
+
+@pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0"])
+def test_gpu_front_end_matches_reference_program(exe, name, tmp_path):
+    src = os.path.join(RUNS, name)
+    _run(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert same_bits(got, want), "trajectory diverged from the reference (a decision flipped)"
+    for f in ("e_vpi.out", "et_vpi.out"):
+        assert _close(tmp_path / f, os.path.join(src, f)), f
+    # histograms depend on the worldline only: identical files
+    for f in ("gr_vpi.out", "sk_vpi.out", "nr_vpi.out"):
+        if os.path.exists(os.path.join(src, f)):
+            assert open(os.path.join(src, f), "rb").read() == open(tmp_path / f, "rb").read(), f
+    assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
+
+
+def test_gpu_lockstep_walkers(exe, tmp_path):
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
+    _run(exe, base + "&gpu\n n_walkers = 3, device = 0\n/\n", str(tmp_path))
+    got = np.fromfile(tmp_path / "worldlines_final.bin")
+    for w, seed in enumerate((1982, 1983, 1984)):
+        src = os.path.join(RUNS, f"he4_worm_s{seed}")
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        assert same_bits(got.reshape((3,) + want.shape)[w], want), w
+        assert _close(tmp_path / f"e_vpi.w{w:04d}.out", os.path.join(src, "e_vpi.out"))
+        assert _close(tmp_path / f"et_vpi.w{w:04d}.out", os.path.join(src, "et_vpi.out"))

@@ -1,0 +1,82 @@
+"""The vpi.in-driven front end (host/pigs_vpi.f90) against output files of the reference PROGRAM
+(tests/golden/vpi_runs, produced by oracle/_ref/vpi): byte-identical observable files and a
+bit-identical final worldline, for diagonal + worm sectors, staging + bisection sampling, trap and
+PBC, and for several lock-step walkers (walker w == the reference run with seed+w).
+Host logic only here: the C ABI is served by tests/shim (CPU oracle).  tests/test_gpu_host.py runs
+the same comparison through libpigs_hip.so on the MI355X."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import same_bits
+from hostlib import build_cpu_host
+
+RUNS = os.path.join(GOLDEN, "vpi_runs")
+FILES = ["e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out"]
+
+
+def run_pigs_vpi(exe, vpi_in_text, workdir, env=None):
+    with open(os.path.join(workdir, "vpi.in"), "w") as f:
+        f.write(vpi_in_text)
+    with open(os.path.join(workdir, "vpi.in")) as fin, open(os.path.join(workdir, "stdout.txt"), "w") as fo:
+        r = subprocess.run([exe], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=workdir, timeout=900, env=env)
+    assert r.returncode == 0, open(os.path.join(workdir, "stdout.txt")).read()[-2000:]
+
+
+def final_worldline(workdir, shape, W=1):
+    a = np.fromfile(os.path.join(workdir, "worldlines_final.bin"))
+    return a.reshape((W,) + shape)
+
+
+@pytest.fixture(scope="module")
+def exe():
+    return build_cpu_host()[2]
+
+
+@pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0"])
+def test_front_end_reproduces_reference_files(exe, name, tmp_path):
+    src = os.path.join(RUNS, name)
+    run_pigs_vpi(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))
+    for f in FILES:
+        if os.path.exists(os.path.join(src, f)):
+            assert open(os.path.join(src, f), "rb").read() == open(tmp_path / f, "rb").read(), f
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    assert same_bits(final_worldline(str(tmp_path), want.shape)[0], want)
+    ref_perm = open(os.path.join(src, "fort.99")).read().split()
+    assert open(tmp_path / "perm_vpi.out").read().split() == ref_perm
+
+
+def test_lockstep_walkers_reproduce_per_seed_reference_runs(exe, tmp_path):
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
+    run_pigs_vpi(exe, base + "&gpu\n n_walkers = 3, device = 0\n/\n", str(tmp_path))
+    for w, seed in enumerate((1982, 1983, 1984)):
+        src = os.path.join(RUNS, f"he4_worm_s{seed}")
+        for f in FILES:
+            mine = tmp_path / f.replace(".out", f".w{w:04d}.out")
+            assert open(os.path.join(src, f), "rb").read() == open(mine, "rb").read(), (w, f)
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        assert same_bits(final_worldline(str(tmp_path), want.shape, 3)[w], want)
+    # the unsuffixed files hold the walker average of the block values
+    av = np.loadtxt(tmp_path / "e_vpi.out")
+    per = [np.loadtxt(tmp_path / f"e_vpi.w{w:04d}.out") for w in range(3)]
+    blocks = sorted(set(int(b) for p in per for b in np.atleast_2d(p)[:, 0]))
+    assert len(av) == len(blocks)
+
+
+def test_reference_program_itself_if_present(exe, tmp_path):
+    """Where the reference build exists, run it fresh on a new input and compare again."""
+    from oracle.pyoracle import REF_VPI
+    if not os.path.exists(REF_VPI):
+        pytest.skip("oracle/_ref/vpi not built here")
+    txt = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read().replace("seed = 1982", "seed = 4242") \
+        .replace("Nstep = 25", "Nstep = 15")
+    a, b = tmp_path / "ref", tmp_path / "mine"
+    a.mkdir(); b.mkdir()
+    run_pigs_vpi(REF_VPI, txt, str(a))
+    run_pigs_vpi(exe, txt, str(b))
+    for f in FILES:
+        assert open(a / f, "rb").read() == open(b / f, "rb").read(), f
