@@ -97,6 +97,20 @@ int pigs_delta_action_batch(pigs_ctx *ctx, int64_t n_items,
 int pigs_delta_action_batch_dev(pigs_ctx *ctx, int64_t n_items,
                                 const int32_t *d_walker, const int32_t *d_ip, const int32_t *d_ib,
                                 const double *d_xnew, const double *d_xold, double *d_DeltaS);
+/* Latency-critical form for a host-driven sampler: the library owns PINNED, device-mapped
+ * staging arrays that the host fills and the kernels read in place over PCIe (no memcpy calls);
+ * DeltaS is written by the kernel straight into pinned host memory.  pigs_stage_reserve returns
+ * (and, when growing, preserves the first `keep` items of) the item arrays;
+ * pigs_delta_action_staged evaluates items [0,n) and returns when DeltaS[0,n) is valid. */
+int pigs_stage_reserve(pigs_ctx *ctx, int64_t capacity, int64_t keep, int32_t **walker, int32_t **ip,
+                       int32_t **ib, double **xnew, double **xold, double **DeltaS);
+int pigs_delta_action_staged(pigs_ctx *ctx, int64_t n_items);
+/* Same for commits: arrays (walker, ip, ib, x); pigs_commit_staged is asynchronous -- the arrays
+ * may be rewritten only after the next synchronous call on this context has returned. */
+int pigs_commit_reserve(pigs_ctx *ctx, int64_t capacity, int64_t keep, int32_t **walker, int32_t **ip,
+                        int32_t **ib, double **x);
+int pigs_commit_staged(pigs_ctx *ctx, int64_t n);
+
 /* Test hook: the components UpdateAction combines (DeltaPot, DeltaF2, DeltaLogPsi), 3 per item. */
 int pigs_delta_action_parts(pigs_ctx *ctx, int64_t n_items,
                             const int32_t *walker, const int32_t *ip, const int32_t *ib,

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "pigs_therm_energy_batch", "pigs_local_energy_batch", "pigs_comm_unique_id",
     "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
     "pigs_set_tuning", "pigs_selftest_fastmath",
+    "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
 ]
 
 
@@ -85,6 +86,10 @@ def load_library(path=LIB_PATH):
     L.pigs_comm_init_rank.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
     L.pigs_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32]
     L.pigs_estimators_allreduce.argtypes = [vp, _dp, C.c_int32]
+    L.pigs_stage_reserve.argtypes = [vp, C.c_int64, C.c_int64] + [C.POINTER(_ip)] * 3 + [C.POINTER(_dp)] * 3
+    L.pigs_delta_action_staged.argtypes = [vp, C.c_int64]
+    L.pigs_commit_reserve.argtypes = [vp, C.c_int64, C.c_int64] + [C.POINTER(_ip)] * 3 + [C.POINTER(_dp)]
+    L.pigs_commit_staged.argtypes = [vp, C.c_int64]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     for name in ABI_SYMBOLS:
@@ -223,6 +228,35 @@ class PigsContext:
         _chk(self.L, self.L.pigs_delta_action_batch(self.h, n, _i(walker), _i(ip), _i(ib), _d(xnew),
                                                     _d(xold), _d(out)), "pigs_delta_action_batch")
         return out
+
+    def delta_action_staged(self, walker, ip, ib, xnew, xold):
+        """Same through the pinned staging arrays (the sampler's low-latency path)."""
+        walker, ip, ib = _i32(walker).ravel(), _i32(ip).ravel(), _i32(ib).ravel()
+        n, d = walker.size, self.cfg.dim
+        pw, pp, pb = _ip(), _ip(), _ip()
+        pxn, pxo, pds = _dp(), _dp(), _dp()
+        _chk(self.L, self.L.pigs_stage_reserve(self.h, max(n, 1), 0, C.byref(pw), C.byref(pp), C.byref(pb),
+                                               C.byref(pxn), C.byref(pxo), C.byref(pds)), "pigs_stage_reserve")
+        np.ctypeslib.as_array(pw, (max(n, 1),))[:n] = walker
+        np.ctypeslib.as_array(pp, (max(n, 1),))[:n] = ip
+        np.ctypeslib.as_array(pb, (max(n, 1),))[:n] = ib
+        np.ctypeslib.as_array(pxn, (max(n, 1) * d,))[:n * d] = _f64(xnew).ravel()
+        np.ctypeslib.as_array(pxo, (max(n, 1) * d,))[:n * d] = _f64(xold).ravel()
+        _chk(self.L, self.L.pigs_delta_action_staged(self.h, n), "pigs_delta_action_staged")
+        return np.ctypeslib.as_array(pds, (max(n, 1),))[:n].copy()
+
+    def commit_staged(self, walker, ip, ib, x):
+        walker, ip, ib = _i32(walker).ravel(), _i32(ip).ravel(), _i32(ib).ravel()
+        n, d = walker.size, self.cfg.dim
+        pw, pp, pb, px = _ip(), _ip(), _ip(), _dp()
+        _chk(self.L, self.L.pigs_commit_reserve(self.h, max(n, 1), 0, C.byref(pw), C.byref(pp), C.byref(pb),
+                                                C.byref(px)), "pigs_commit_reserve")
+        np.ctypeslib.as_array(pw, (max(n, 1),))[:n] = walker
+        np.ctypeslib.as_array(pp, (max(n, 1),))[:n] = ip
+        np.ctypeslib.as_array(pb, (max(n, 1),))[:n] = ib
+        np.ctypeslib.as_array(px, (max(n, 1) * d,))[:n * d] = _f64(x).ravel()
+        _chk(self.L, self.L.pigs_commit_staged(self.h, n), "pigs_commit_staged")
+        self.sync()
 
     def delta_action_parts(self, walker, ip, ib, xnew, xold):
         """(DeltaPot, DeltaF2, DeltaLogPsi) per item: UpdatePot / UpdateWf outputs."""

@@ -59,6 +59,26 @@ struct DevBuf {
 
 } // namespace
 
+// pinned, device-mapped host arrays of the staged (low-latency) entry points
+struct PinBuf {
+    void *h = nullptr, *d = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t want, size_t keep_bytes)
+    {
+        if (want <= bytes) return hipSuccess;
+        void *nh = nullptr, *nd = nullptr;
+        hipError_t e = hipHostMalloc(&nh, want, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(&nd, nh, 0);
+        if (e != hipSuccess) { (void)hipHostFree(nh); return e; }
+        if (h && keep_bytes) memcpy(nh, h, keep_bytes < bytes ? keep_bytes : bytes);
+        if (h) (void)hipHostFree(h);
+        h = nh; d = nd; bytes = want;
+        return hipSuccess;
+    }
+    void release() { if (h) (void)hipHostFree(h); h = d = nullptr; bytes = 0; }
+};
+
 struct pigs_ctx {
     pigs_params hp;
     DevParams   P;
@@ -72,6 +92,9 @@ struct pigs_ctx {
     DevBuf<double>  d_xnew, d_xold, d_out, d_parts, d_stage, d_slices, d_res;
     pigs_comm  *comm = nullptr;
     int         k1_variant = K1_AUTO;
+    PinBuf      st_w, st_ip, st_ib, st_xn, st_xo, st_out;      // staged items
+    PinBuf      cs_w, cs_ip, cs_ib, cs_x;                      // staged commits
+    int64_t     st_cap = 0, cs_cap = 0;
 };
 
 static int check_ctx(pigs_ctx *c)
@@ -168,6 +191,8 @@ int pigs_ctx_destroy(pigs_ctx *c)
     c->d_walker.release(); c->d_ip.release(); c->d_ib.release(); c->d_slotw.release(); c->d_slotb.release();
     c->d_xnew.release(); c->d_xold.release(); c->d_out.release(); c->d_parts.release();
     c->d_stage.release(); c->d_slices.release(); c->d_res.release();
+    c->st_w.release(); c->st_ip.release(); c->st_ib.release(); c->st_xn.release(); c->st_xo.release(); c->st_out.release();
+    c->cs_w.release(); c->cs_ip.release(); c->cs_ib.release(); c->cs_x.release();
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_VT) (void)hipFree(c->d_VT);
     if (c->d_WF) (void)hipFree(c->d_WF);
@@ -322,6 +347,74 @@ int pigs_delta_action_batch_dev(pigs_ctx *c, int64_t n, const int32_t *d_walker,
     // indices are range-checked on the device (out-of-range items produce NaN, never a fault)
     HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n, d_walker, d_ip, d_ib,
                                d_xnew, d_xold, d_DeltaS, nullptr, c->stream));
+    return PIGS_OK;
+}
+
+// ---- staged (pinned, zero-copy) forms --------------------------------------------------------
+int pigs_stage_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **walker, int32_t **ip, int32_t **ib,
+                       double **xnew, double **xold, double **DeltaS)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (cap < 1 || cap > 0x7fffffff || keep < 0 || !walker || !ip || !ib || !xnew || !xold || !DeltaS)
+        return fail(PIGS_ERR_ARG, "bad stage_reserve arguments");
+    if (cap > c->st_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const size_t d = c->P.dim, k = (size_t)(keep < c->st_cap ? keep : c->st_cap);
+        HIPCHK(c->st_w.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->st_ip.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->st_ib.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->st_xn.reserve(cap * d * sizeof(double), k * d * sizeof(double)));
+        HIPCHK(c->st_xo.reserve(cap * d * sizeof(double), k * d * sizeof(double)));
+        HIPCHK(c->st_out.reserve(cap * sizeof(double), k * sizeof(double)));
+        c->st_cap = cap;
+    }
+    *walker = (int32_t *)c->st_w.h; *ip = (int32_t *)c->st_ip.h; *ib = (int32_t *)c->st_ib.h;
+    *xnew = (double *)c->st_xn.h; *xold = (double *)c->st_xo.h; *DeltaS = (double *)c->st_out.h;
+    return PIGS_OK;
+}
+
+int pigs_delta_action_staged(pigs_ctx *c, int64_t n)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || n > c->st_cap) return fail(PIGS_ERR_ARG, "n_items=%lld exceeds the staged capacity %lld", (long long)n, (long long)c->st_cap);
+    if (n == 0) return PIGS_OK;
+    // indices are range-checked on the device (bad item -> NaN)
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n,
+                               (const int32_t *)c->st_w.d, (const int32_t *)c->st_ip.d, (const int32_t *)c->st_ib.d,
+                               (const double *)c->st_xn.d, (const double *)c->st_xo.d, (double *)c->st_out.d,
+                               nullptr, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_commit_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **walker, int32_t **ip, int32_t **ib, double **x)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (cap < 1 || cap > 0x7fffffff || keep < 0 || !walker || !ip || !ib || !x) return fail(PIGS_ERR_ARG, "bad commit_reserve arguments");
+    if (cap > c->cs_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const size_t d = c->P.dim, k = (size_t)(keep < c->cs_cap ? keep : c->cs_cap);
+        HIPCHK(c->cs_w.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->cs_ip.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->cs_ib.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
+        HIPCHK(c->cs_x.reserve(cap * d * sizeof(double), k * d * sizeof(double)));
+        c->cs_cap = cap;
+    }
+    *walker = (int32_t *)c->cs_w.h; *ip = (int32_t *)c->cs_ip.h; *ib = (int32_t *)c->cs_ib.h; *x = (double *)c->cs_x.h;
+    return PIGS_OK;
+}
+
+int pigs_commit_staged(pigs_ctx *c, int64_t n)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || n > c->cs_cap) return fail(PIGS_ERR_ARG, "n=%lld exceeds the staged capacity %lld", (long long)n, (long long)c->cs_cap);
+    if (n == 0) return PIGS_OK;
+    const int32_t *w = (const int32_t *)c->cs_w.h, *ip = (const int32_t *)c->cs_ip.h, *ib = (const int32_t *)c->cs_ib.h;
+    for (int64_t i = 0; i < n; ++i)
+        if (w[i] < 0 || w[i] >= c->n_walkers || ip[i] < 1 || ip[i] > c->P.Np || ib[i] < 0 || ib[i] >= c->P.M)
+            return fail(PIGS_ERR_ARG, "commit %lld: walker=%d ip=%d ib=%d out of range", (long long)i, w[i], ip[i], ib[i]);
+    HIPCHK(launch_commit_beads(c->P, c->d_paths, n, (const int32_t *)c->cs_w.d, (const int32_t *)c->cs_ip.d,
+                               (const int32_t *)c->cs_ib.d, (const double *)c->cs_x.d, c->stream));
     return PIGS_OK;
 }
 

@@ -117,6 +117,38 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_delta_action_batch
 
+     ! pinned, device-mapped staging arrays owned by the library (low-latency sampler path)
+     function pigs_stage_reserve(ctx,capacity,keep,walker,ip,ib,xnew,xold,DeltaS) &
+          & bind(C,name='pigs_stage_reserve') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int64_t), value :: capacity,keep
+       type(c_ptr), intent(out)  :: walker,ip,ib,xnew,xold,DeltaS
+       integer(c_int) :: rc
+     end function pigs_stage_reserve
+
+     function pigs_delta_action_staged(ctx,n_items) bind(C,name='pigs_delta_action_staged') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int64_t), value :: n_items
+       integer(c_int) :: rc
+     end function pigs_delta_action_staged
+
+     function pigs_commit_reserve(ctx,capacity,keep,walker,ip,ib,x) bind(C,name='pigs_commit_reserve') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int64_t), value :: capacity,keep
+       type(c_ptr), intent(out)  :: walker,ip,ib,x
+       integer(c_int) :: rc
+     end function pigs_commit_reserve
+
+     function pigs_commit_staged(ctx,n) bind(C,name='pigs_commit_staged') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int64_t), value :: n
+       integer(c_int) :: rc
+     end function pigs_commit_staged
+
      function pigs_delta_action_parts(ctx,n_items,walker,ip,ib,xnew,xold,parts) &
           & bind(C,name='pigs_delta_action_parts') result(rc)
        import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr

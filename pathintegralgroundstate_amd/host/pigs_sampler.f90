@@ -50,19 +50,22 @@ module pigs_sampler
      type(c_ptr) :: ctx = c_null_ptr
      ! ---- proposal items of the current stage (SoA, as the C ABI takes them)
      integer :: n_items = 0, cap = 0
-     integer(c_int32_t), allocatable :: it_w(:), it_ip(:), it_ib(:)
-     real(c_double), allocatable     :: it_xnew(:,:), it_xold(:,:), it_dS(:), it_wgt(:)
+     ! (views of the library's pinned, device-mapped staging arrays: the kernel reads them in place)
+     integer(c_int32_t), pointer :: it_w(:) => null(), it_ip(:) => null(), it_ib(:) => null()
+     real(c_double), pointer     :: it_xnew(:,:) => null(), it_xold(:,:) => null(), it_dS(:) => null()
+     real(c_double), allocatable :: it_wgt(:)
      ! ---- beads to write to the device before the next evaluation
      integer :: n_commit = 0, ccap = 0
-     integer(c_int32_t), allocatable :: cm_w(:), cm_ip(:), cm_ib(:)
-     real(c_double), allocatable     :: cm_x(:,:)
+     integer(c_int32_t), pointer :: cm_w(:) => null(), cm_ip(:) => null(), cm_ib(:) => null()
+     real(c_double), pointer     :: cm_x(:,:) => null()
      ! ---- per-walker bookkeeping of the move in flight
-     integer, allocatable :: first(:), cnt(:), seg_i(:), seg_e(:), aux_i(:), aux_k(:)
+     integer, allocatable :: first(:), cnt(:), want(:), seg_i(:), seg_e(:), aux_i(:), aux_k(:)
      logical, allocatable :: alive(:), flag(:)
      real(8), allocatable :: S0(:), DK(:)
      real(8), allocatable :: Old(:,:,:), Old2(:,:,:)  ! (dim,0:2*Nb,W) saved chains
      ! ---- statistics
      integer(8) :: n_eval_items = 0, n_eval_calls = 0
+     real(8)    :: t_eval = 0.d0         ! wall seconds spent inside the batched Delta-S calls
   end type sampler_t
 
 contains
@@ -81,13 +84,13 @@ contains
     s%dt = dt; s%density = density; s%CWorm = CWorm; s%ctx = ctx
     s%pi = acos(-1.d0)
     s%n_items = 0; s%cap = 0; s%n_commit = 0; s%ccap = 0
-    s%n_eval_items = 0; s%n_eval_calls = 0
+    s%n_eval_items = 0; s%n_eval_calls = 0; s%t_eval = 0.d0
     do k=1,dim
        s%Lbox(k) = Lbox(k)
        s%LboxHalf(k) = 0.5d0*Lbox(k)
     end do
     allocate(s%Path(dim,Np,0:2*Nb,W), s%xend(dim,2,W), s%isopen(W), s%iworm(W), s%rng(W))
-    allocate(s%first(W), s%cnt(W), s%seg_i(W), s%seg_e(W), s%aux_i(W), s%aux_k(W))
+    allocate(s%first(W), s%cnt(W), s%want(W), s%seg_i(W), s%seg_e(W), s%aux_i(W), s%aux_k(W))
     allocate(s%alive(W), s%flag(W), s%S0(W), s%DK(W))
     allocate(s%Old(dim,0:2*Nb,W), s%Old2(dim,0:2*Nb,W))
     s%isopen = .false.; s%iworm = 0; s%Path = 0.d0; s%xend = 0.d0
@@ -97,10 +100,10 @@ contains
 
   subroutine sampler_free(s)
     type(sampler_t), intent(inout) :: s
-    if (allocated(s%Path)) deallocate(s%Path,s%xend,s%isopen,s%iworm,s%rng,s%first,s%cnt, &
+    if (allocated(s%Path)) deallocate(s%Path,s%xend,s%isopen,s%iworm,s%rng,s%first,s%cnt,s%want, &
          & s%seg_i,s%seg_e,s%aux_i,s%aux_k,s%alive,s%flag,s%S0,s%DK,s%Old,s%Old2)
-    if (allocated(s%it_w)) deallocate(s%it_w,s%it_ip,s%it_ib,s%it_xnew,s%it_xold,s%it_dS,s%it_wgt)
-    if (allocated(s%cm_w)) deallocate(s%cm_w,s%cm_ip,s%cm_ib,s%cm_x)
+    if (allocated(s%it_wgt)) deallocate(s%it_wgt)
+    nullify(s%it_w,s%it_ip,s%it_ib,s%it_xnew,s%it_xold,s%it_dS,s%cm_w,s%cm_ip,s%cm_ib,s%cm_x)   ! owned by the context
     s%cap = 0; s%ccap = 0
   end subroutine sampler_free
 
@@ -116,43 +119,40 @@ contains
   subroutine sampler_flush(s)
     type(sampler_t), intent(inout) :: s
     call flush_commits(s)
+    ! the staged commit is asynchronous: make sure it has consumed its arrays before they are reused
+    call pigs_check(pigs_sync(s%ctx),'pigs_sync')
   end subroutine sampler_flush
 
   subroutine grow_items(s,n)
     type(sampler_t), intent(inout) :: s
     integer, intent(in) :: n
-    integer(c_int32_t), allocatable :: a(:),b(:),c(:)
-    real(c_double), allocatable :: xn(:,:),xo(:,:),d(:),g(:)
+    type(c_ptr) :: pw,pi,pb,pxn,pxo,pds
+    real(c_double), allocatable :: g(:)
     integer :: m
     if (n<=s%cap) return
     m = max(n,2*s%cap)
-    allocate(a(m),b(m),c(m),xn(s%dim,m),xo(s%dim,m),d(m),g(m))
-    if (s%n_items>0) then
-       a(1:s%n_items) = s%it_w(1:s%n_items);  b(1:s%n_items) = s%it_ip(1:s%n_items)
-       c(1:s%n_items) = s%it_ib(1:s%n_items); g(1:s%n_items) = s%it_wgt(1:s%n_items)
-       xn(:,1:s%n_items) = s%it_xnew(:,1:s%n_items); xo(:,1:s%n_items) = s%it_xold(:,1:s%n_items)
-    end if
-    call move_alloc(a,s%it_w); call move_alloc(b,s%it_ip); call move_alloc(c,s%it_ib)
-    call move_alloc(xn,s%it_xnew); call move_alloc(xo,s%it_xold)
-    call move_alloc(d,s%it_dS); call move_alloc(g,s%it_wgt)
+    call pigs_check(pigs_stage_reserve(s%ctx,int(m,c_int64_t),int(s%n_items,c_int64_t),pw,pi,pb,pxn,pxo,pds), &
+         & 'pigs_stage_reserve')
+    call c_f_pointer(pw,s%it_w,[m]);  call c_f_pointer(pi,s%it_ip,[m]); call c_f_pointer(pb,s%it_ib,[m])
+    call c_f_pointer(pxn,s%it_xnew,[s%dim,m]); call c_f_pointer(pxo,s%it_xold,[s%dim,m])
+    call c_f_pointer(pds,s%it_dS,[m])
+    allocate(g(m))
+    if (s%n_items>0) g(1:s%n_items) = s%it_wgt(1:s%n_items)
+    call move_alloc(g,s%it_wgt)
     s%cap = m
   end subroutine grow_items
 
   subroutine grow_commit(s,n)
     type(sampler_t), intent(inout) :: s
     integer, intent(in) :: n
-    integer(c_int32_t), allocatable :: a(:),b(:),c(:)
-    real(c_double), allocatable :: x(:,:)
+    type(c_ptr) :: pw,pi,pb,px
     integer :: m
     if (n<=s%ccap) return
     m = max(n,2*s%ccap)
-    allocate(a(m),b(m),c(m),x(s%dim,m))
-    if (s%n_commit>0) then
-       a(1:s%n_commit) = s%cm_w(1:s%n_commit); b(1:s%n_commit) = s%cm_ip(1:s%n_commit)
-       c(1:s%n_commit) = s%cm_ib(1:s%n_commit); x(:,1:s%n_commit) = s%cm_x(:,1:s%n_commit)
-    end if
-    call move_alloc(a,s%cm_w); call move_alloc(b,s%cm_ip); call move_alloc(c,s%cm_ib)
-    call move_alloc(x,s%cm_x)
+    call pigs_check(pigs_commit_reserve(s%ctx,int(m,c_int64_t),int(s%n_commit,c_int64_t),pw,pi,pb,px), &
+         & 'pigs_commit_reserve')
+    call c_f_pointer(pw,s%cm_w,[m]); call c_f_pointer(pi,s%cm_ip,[m]); call c_f_pointer(pb,s%cm_ib,[m])
+    call c_f_pointer(px,s%cm_x,[s%dim,m])
     s%ccap = m
   end subroutine grow_commit
 
@@ -216,16 +216,29 @@ contains
     end do
   end function link_r2
 
+  ! item slots of a stage are planned per walker (plan_items) so that walkers can generate their
+  ! proposals concurrently: walker w owns slots first(w) .. first(w)+want(w)-1
+  subroutine plan_items(s)
+    type(sampler_t), intent(inout) :: s
+    integer :: w,n
+    n = 0
+    do w=1,s%W
+       s%first(w) = n+1
+       s%cnt(w)   = 0
+       n = n+s%want(w)
+    end do
+    call grow_items(s,n)
+    s%n_items = n
+  end subroutine plan_items
+
   subroutine add_item(s,w,ip,ib,xnew,xold,wgt)
     type(sampler_t), intent(inout) :: s
     integer, intent(in) :: w,ip,ib
     real(8), intent(in) :: xnew(s%dim),xold(s%dim),wgt
     integer :: n
-    if (s%n_items+1>s%cap) call grow_items(s,s%n_items+1)
-    n = s%n_items+1
+    n = s%first(w)+s%cnt(w)
     s%it_w(n) = w-1; s%it_ip(n) = ip; s%it_ib(n) = ib
     s%it_xnew(:,n) = xnew; s%it_xold(:,n) = xold; s%it_wgt(n) = wgt
-    s%n_items = n
     s%cnt(w) = s%cnt(w)+1
   end subroutine add_item
 
@@ -253,8 +266,7 @@ contains
   subroutine flush_commits(s)
     type(sampler_t), intent(inout) :: s
     if (s%n_commit==0) return
-    call pigs_check(pigs_commit_beads(s%ctx,int(s%n_commit,c_int64_t),s%cm_w,s%cm_ip,s%cm_ib,s%cm_x), &
-         & 'pigs_commit_beads')
+    call pigs_check(pigs_commit_staged(s%ctx,int(s%n_commit,c_int64_t)),'pigs_commit_staged')
     s%n_commit = 0
   end subroutine flush_commits
 
@@ -262,16 +274,20 @@ contains
     type(sampler_t), intent(inout) :: s
     s%n_items = 0
     s%cnt = 0
+    s%want = 0
     s%first = 1
   end subroutine begin_stage
 
   ! (B): every queued item through the GPU
   subroutine evaluate(s)
     type(sampler_t), intent(inout) :: s
+    integer(8) :: c0,c1,rate
     call flush_commits(s)
     if (s%n_items==0) return
-    call pigs_check(pigs_delta_action_batch(s%ctx,int(s%n_items,c_int64_t),s%it_w,s%it_ip,s%it_ib, &
-         & s%it_xnew,s%it_xold,s%it_dS),'pigs_delta_action_batch')
+    call system_clock(c0,rate)
+    call pigs_check(pigs_delta_action_staged(s%ctx,int(s%n_items,c_int64_t)),'pigs_delta_action_staged')
+    call system_clock(c1)
+    s%t_eval = s%t_eval+dble(c1-c0)/dble(rate)
     s%n_eval_items = s%n_eval_items+s%n_items
     s%n_eval_calls = s%n_eval_calls+1
   end subroutine evaluate
@@ -443,10 +459,12 @@ contains
     integer :: w,ib,k,ip
     real(8) :: dx(s%dim),xold(s%dim),xnew(s%dim)
     call begin_stage(s)
+    where (active) s%want = 2*s%Nb+1
+    call plan_items(s)
+    !$omp parallel do schedule(static) private(ip,k,ib,dx,xold,xnew)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = ip_of(w)
-       s%first(w) = s%n_items+1
        do k=1,s%dim
           dx(k) = delta*(2.d0*mt_real(s%rng(w))-1.d0)
        end do
@@ -462,6 +480,7 @@ contains
        end do
        s%S0(w) = 0.d0
     end do
+    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_translate
@@ -499,12 +518,17 @@ contains
     do ilev=1,maxlev
        call begin_stage(s)
        do w=1,s%W
+          if (s%alive(w) .and. ilev<=s%aux_i(w)) s%want(w) = 2**(ilev-1)
+       end do
+       call plan_items(s)
+       if (s%n_items==0) exit
+       !$omp parallel do schedule(static)
+       do w=1,s%W
           if (.not. s%alive(w)) cycle
           if (ilev>s%aux_i(w)) cycle
-          s%first(w) = s%n_items+1
           call gen_bisection_level(s,w,ip_of(w),s%seg_i(w),s%aux_i(w),ilev)
        end do
-       if (s%n_items==0) exit
+       !$omp end parallel do
        call evaluate(s)
        do w=1,s%W
           if (.not. s%alive(w)) cycle
@@ -535,6 +559,9 @@ contains
     integer :: w,nl,ii,ie
     real(8) :: t
     call begin_stage(s)
+    where (active) s%want = 1
+    call plan_items(s)
+    !$omp parallel do schedule(static) private(nl,ii,ie)
     do w=1,s%W
        s%alive(w) = active(w)
        if (.not. active(w)) cycle
@@ -547,13 +574,13 @@ contains
        end if
        ie = ii+2**nl
        call save_chain(s,w,ip_of(w),ii,ie)
-       s%first(w) = s%n_items+1
        if (which==HEAD) then
           call gen_end_guess(s,w,ip_of(w),ii,ie,2**nl,+1,1.d0)
        else
           call gen_end_guess(s,w,ip_of(w),ie,ii,2**nl,-1,1.d0)
        end if
     end do
+    !$omp end parallel do
     call evaluate(s)
     do w=1,s%W
        if (.not. active(w)) cycle
@@ -572,14 +599,17 @@ contains
     integer, intent(inout) :: accepted(s%W)
     integer :: w,ii
     call begin_stage(s)
+    where (active) s%want = Lstag-1
+    call plan_items(s)
+    !$omp parallel do schedule(static) private(ii)
     do w=1,s%W
        if (.not. active(w)) cycle
        ii = int((2*s%Nb-Lstag+1)*mt_real(s%rng(w)))
        call save_chain(s,w,ip_of(w),ii,ii+Lstag)
-       s%first(w) = s%n_items+1
        call gen_staging(s,w,ip_of(w),ii,Lstag)
        s%S0(w) = 0.d0
     end do
+    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_staging
@@ -595,7 +625,14 @@ contains
     call begin_stage(s)
     do w=1,s%W
        if (.not. active(w)) cycle
-       Ls = int((Lmax-1)*mt_real(s%rng(w)))+2
+       s%aux_i(w) = int((Lmax-1)*mt_real(s%rng(w)))+2
+       s%want(w)  = s%aux_i(w)
+    end do
+    call plan_items(s)
+    !$omp parallel do schedule(static) private(Ls,ii,ie)
+    do w=1,s%W
+       if (.not. active(w)) cycle
+       Ls = s%aux_i(w)
        if (which==HEAD) then
           ii = 0
        else
@@ -603,7 +640,6 @@ contains
        end if
        ie = ii+Ls
        call save_chain(s,w,ip_of(w),ii,ie)
-       s%first(w) = s%n_items+1
        if (which==HEAD) then
           call gen_end_guess(s,w,ip_of(w),ii,ie,Ls,+1,1.d0)
        else
@@ -612,6 +648,7 @@ contains
        call gen_staging(s,w,ip_of(w),ii,Ls)
        s%S0(w) = 0.d0
     end do
+    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_end_staging
@@ -654,6 +691,8 @@ contains
     integer :: w,ib,k,ip,ibi,ibf
     real(8) :: dx(s%dim),xold(s%dim),xnew(s%dim)
     call begin_stage(s)
+    where (active) s%want = s%Nb+1
+    call plan_items(s)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = s%iworm(w)
@@ -667,7 +706,6 @@ contains
           ibi = s%Nb; ibf = 2*s%Nb
        end if
        call save_chain(s,w,ip,ibi,ibf)
-       s%first(w) = s%n_items+1
        do ib=ibi,ibf
           do k=1,s%dim
              xold(k) = s%Path(k,ip,ib,w)
@@ -691,6 +729,8 @@ contains
     integer, intent(inout) :: accepted(s%W)
     integer :: w,ii,ip
     call begin_stage(s)
+    where (active) s%want = Lstag-1
+    call plan_items(s)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = s%iworm(w)
@@ -698,7 +738,6 @@ contains
        ii = int((s%Nb-Lstag+1)*mt_real(s%rng(w)))
        if (half==2) ii = ii+s%Nb
        call save_chain(s,w,ip,ii,ii+Lstag)
-       s%first(w) = s%n_items+1
        call gen_staging(s,w,ip,ii,Lstag)
        s%S0(w) = 0.d0
     end do
@@ -718,8 +757,14 @@ contains
     call begin_stage(s)
     do w=1,s%W
        if (.not. active(w)) cycle
+       s%aux_i(w) = int((Lmax-1)*mt_real(s%rng(w)))+2
+       s%want(w)  = s%aux_i(w)
+    end do
+    call plan_items(s)
+    do w=1,s%W
+       if (.not. active(w)) cycle
        ip = s%iworm(w)
-       Ls = int((Lmax-1)*mt_real(s%rng(w)))+2
+       Ls = s%aux_i(w)
        call select_half(s,w,ip,half)
        if (which==HEAD) then
           ii = 0
@@ -734,7 +779,6 @@ contains
        end if
        ie = ii+Ls
        call save_chain(s,w,ip,ii,ie)
-       s%first(w) = s%n_items+1
        if (which==HEAD) then
           call gen_end_guess(s,w,ip,ii,ie,Ls,+1,wgt)
        else
@@ -767,10 +811,17 @@ contains
     call begin_stage(s)
     do w=1,s%W
        if (.not. active(w)) cycle
+       s%aux_i(w) = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
+       s%aux_k(w) = int(mt_real(s%rng(w))*2)+1
+       s%want(w)  = s%aux_i(w)
+    end do
+    call plan_items(s)
+    !$omp parallel do schedule(static) private(ip,Ls,half,ii,ie)
+    do w=1,s%W
+       if (.not. active(w)) cycle
        ip   = ip_of(w)
-       Ls   = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
-       half = int(mt_real(s%rng(w))*2)+1
-       s%aux_k(w) = half
+       Ls   = s%aux_i(w)
+       half = s%aux_k(w)
        s%S0(w) = -log(s%CWorm*s%density)
        if (half==1) then
           ii = s%Nb-Ls; ie = s%Nb
@@ -779,7 +830,6 @@ contains
        end if
        s%DK(w) = delta_k(s,link_r2(s,s%Path(:,ip,ii,w),s%Path(:,ip,ie,w)),Ls)
        call save_chain(s,w,ip,ii,ie)
-       s%first(w) = s%n_items+1
        if (half==1) then
           call gen_end_guess(s,w,ip,ie,ii,Ls,-1,0.5d0)
        else
@@ -787,6 +837,7 @@ contains
        end if
        call gen_staging(s,w,ip,ii,Ls)
     end do
+    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,-1)
     do w=1,s%W
@@ -819,9 +870,16 @@ contains
     call begin_stage(s)
     do w=1,s%W
        if (.not. active(w)) cycle
+       s%aux_i(w) = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
+       s%aux_k(w) = int(mt_real(s%rng(w))*2)+1
+       s%want(w)  = s%aux_i(w)
+    end do
+    call plan_items(s)
+    do w=1,s%W
+       if (.not. active(w)) cycle
        ip   = s%iworm(w)
-       Ls   = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
-       half = int(mt_real(s%rng(w))*2)+1
+       Ls   = s%aux_i(w)
+       half = s%aux_k(w)
        s%S0(w) = log(s%CWorm*s%density)
        if (half==1) then
           ii = s%Nb-Ls; ie = s%Nb;      ic = ie
@@ -833,7 +891,6 @@ contains
        xold = s%Old(:,ic,w)
        xnew = s%xend(:,3-half,w)
        s%Path(:,ip,ic,w) = xnew
-       s%first(w) = s%n_items+1
        call add_item(s,w,ip,ic,xnew,xold,0.5d0)
        call gen_staging(s,w,ip,ii,Ls)
        s%DK(w) = delta_k(s,link_r2(s,s%Path(:,ip,ii,w),s%Path(:,ip,ie,w)),Ls)
@@ -886,7 +943,7 @@ contains
        do
           ip  = ip+1
           acc = acc+Pp(ip)/Sw
-          if (uran<=acc) then
+          if (uran<=acc .or. ip==s%Np) then
              ik = ip
              exit
           end if
@@ -899,11 +956,21 @@ contains
        if (.not. (mt_real(s%rng(w))<=Sw/Sk)) cycle
        go(w) = .true.
        s%aux_k(w) = ik
+       s%aux_i(w) = Ls
+       s%want(w)  = Ls-1
+    end do
+    call plan_items(s)
+    do w=1,s%W
+       if (.not. go(w)) cycle
+       iw = s%iworm(w)
+       ik = s%aux_k(w)
+       Ls = s%aux_i(w)
+       ii = s%Nb-Ls
+       ie = s%Nb
        s%Old(:,:,w)  = s%Path(:,ik,:,w)
        s%Old2(:,:,w) = s%Path(:,iw,:,w)
        s%seg_i(w) = ii; s%seg_e(w) = ie
        s%Path(:,ik,ie,w) = s%xend(:,2,w)
-       s%first(w) = s%n_items+1
        call gen_staging(s,w,ik,ii,Ls)
     end do
     call evaluate(s)

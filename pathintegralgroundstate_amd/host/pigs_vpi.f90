@@ -68,6 +68,7 @@ program pigs_vpi
   real(8) :: t0,t1,mE(3),mT(3)
   integer, allocatable :: ue(:),ut(:),uh(:)
   integer :: ueav,utav
+  integer(8) :: c0,c1,crate
   character(len=32) :: suffix
 
   !---------------------------------------------------------------------
@@ -203,7 +204,7 @@ program pigs_vpi
   !=====================================================================
   do iblock=1,Nblock
 
-     call cpu_time(t0)
+     call system_clock(c0,crate)
      try_open = 0; acc_open = 0; try_close = 0; acc_close = 0
      try_cm = 0; acc_cm = 0; try_stag = 0; acc_bd = 0; acc_head = 0; acc_tail = 0
      try_cm_half = 0; acc_cm_half = 0; try_stag_half = 0
@@ -313,6 +314,7 @@ program pigs_vpi
            call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,int(2*Nb,c_int32_t),E2,K1,P1), &
                 & 'pigs_local_energy_batch')
            call pigs_check(pigs_therm_energy_batch(ctx,int(nd,c_int32_t),wl,Et,Kt,Pt),'pigs_therm_energy_batch')
+           !$omp parallel do schedule(static) private(w,E,Pot,Kin)
            do i=1,nd
               w = diag_list(i)
               idiag(w) = idiag(w)+1; idiag_aux(w) = idiag_aux(w)+1; idiag_block(w) = idiag_block(w)+1
@@ -329,6 +331,7 @@ program pigs_vpi
                  call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
               end if
            end do
+           !$omp end parallel do
         end if
 
      end do   ! istep
@@ -367,7 +370,8 @@ program pigs_vpi
         write (ueav,'(5g20.10e3)') real(iblock),mE/nd
         write (utav,'(5g20.10e3)') real(iblock),mT/nd
      end if
-     call cpu_time(t1)
+     call system_clock(c1)
+     t0 = 0.d0; t1 = dble(c1-c0)/dble(crate)
 
      print '(a)',            ' -----------------------------------------------------------'
      print '(a,i8)',         ' BLOCK NUMBER :',iblock
@@ -383,8 +387,8 @@ program pigs_vpi
      print '(a,f7.2,a)',     '   > Open acc          =',100.d0*real(sum(acc_open))/max(real(sum(try_open)),1.0),' %'
      print '(a,f7.2,a)',     '   > Close acc         =',100.d0*real(sum(acc_close))/max(real(sum(try_close)),1.0),' %'
      print '(a,f7.2,a)',     '   > Swap acc          =',100.d0*real(sum(acc_swap))/max(real(sum(try_swap)),1.0),' %'
-     print '(a,f9.2,a,i12,a,i10,a)', '   > Time per block    =',t1-t0,' s;  Delta S items so far',s%n_eval_items, &
-          & ' in',s%n_eval_calls,' batches'
+     print '(a,f9.2,a,i12,a,i10,a,f9.2,a)', '   > Time per block    =',t1-t0,' s;  Delta S items so far',s%n_eval_items, &
+          & ' in',s%n_eval_calls,' batches,',s%t_eval,' s inside them'
 
   end do   ! iblock
 

@@ -20,6 +20,9 @@ struct pigs_ctx {
     int     W;
     size_t  wl;        /* doubles per worldline */
     double *VT, *WF, *paths;
+    int32_t *st_w, *st_ip, *st_ib, *cs_w, *cs_ip, *cs_ib;
+    double  *st_xn, *st_xo, *st_out, *cs_x;
+    int64_t st_cap, cs_cap;
 };
 
 static char g_err[256] = "";
@@ -142,6 +145,40 @@ int pigs_local_energy_batch(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t i
                         &E[i], &K[i], &P[i]);
     return PIGS_OK;
 }
+
+int pigs_stage_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **w, int32_t **ip, int32_t **ib,
+                       double **xn, double **xo, double **dS)
+{
+    (void)keep;
+    if (cap > c->st_cap) {
+        const size_t d = c->s.dim;
+        c->st_w = realloc(c->st_w, cap * 4); c->st_ip = realloc(c->st_ip, cap * 4); c->st_ib = realloc(c->st_ib, cap * 4);
+        c->st_xn = realloc(c->st_xn, cap * d * 8); c->st_xo = realloc(c->st_xo, cap * d * 8);
+        c->st_out = realloc(c->st_out, cap * 8);
+        c->st_cap = cap;
+    }
+    *w = c->st_w; *ip = c->st_ip; *ib = c->st_ib; *xn = c->st_xn; *xo = c->st_xo; *dS = c->st_out;
+    return PIGS_OK;
+}
+
+int pigs_delta_action_staged(pigs_ctx *c, int64_t n)
+{
+    return pigs_delta_action_batch(c, n, c->st_w, c->st_ip, c->st_ib, c->st_xn, c->st_xo, c->st_out);
+}
+
+int pigs_commit_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **w, int32_t **ip, int32_t **ib, double **x)
+{
+    (void)keep;
+    if (cap > c->cs_cap) {
+        c->cs_w = realloc(c->cs_w, cap * 4); c->cs_ip = realloc(c->cs_ip, cap * 4); c->cs_ib = realloc(c->cs_ib, cap * 4);
+        c->cs_x = realloc(c->cs_x, cap * c->s.dim * 8);
+        c->cs_cap = cap;
+    }
+    *w = c->cs_w; *ip = c->cs_ip; *ib = c->cs_ib; *x = c->cs_x;
+    return PIGS_OK;
+}
+
+int pigs_commit_staged(pigs_ctx *c, int64_t n) { return pigs_commit_beads(c, n, c->cs_w, c->cs_ip, c->cs_ib, c->cs_x); }
 
 int pigs_comm_unique_id(char id[128]) { memset(id, 0, 128); return PIGS_OK; }
 int pigs_comm_init_rank(pigs_ctx *c, int32_t n, int32_t r, const char id[128]) { (void)c; (void)n; (void)r; (void)id; return PIGS_OK; }

@@ -261,6 +261,14 @@ def test_commit_swap_and_edge_cases(gpu_lib, oracle):
         Paths[1, S.Nb:, 2] = Paths[1, S.Nb:, 16]
         Paths[1, S.Nb:, 16] = t
         assert same_bits(ctx.download_all(), Paths)
+        # staged (pinned, zero-copy) forms give the same bits as the copying forms
+        w2, ip2, ib2, xn2, xo2 = _random_batch(rng, S, Paths, 777, 0.2)
+        assert same_bits(ctx.delta_action_staged(w2, ip2, ib2, xn2, xo2), ctx.delta_action_batch(w2, ip2, ib2, xn2, xo2))
+        key = (w2.astype(np.int64) * 1000 + ip2) * 1000 + ib2
+        _, first = np.unique(key, return_index=True)
+        ctx.commit_staged(w2[first], ip2[first], ib2[first], xn2[first])
+        Paths[w2[first], ib2[first], ip2[first] - 1] = xn2[first]
+        assert same_bits(ctx.download_all(), Paths)
         # bad indices are refused, not faulted on
         with pytest.raises(gpu_lib.PigsError):
             ctx.delta_action_batch([0], [65], [0], np.zeros((1, 3)), np.zeros((1, 3)))
