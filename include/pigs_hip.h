@@ -123,6 +123,29 @@ int pigs_commit_beads(pigs_ctx *ctx, int64_t n, const int32_t *walker, const int
 /* Swap accept branch, vpi_mod.f90:2454-2464: exchange beads Nb..2Nb of particles iw, ik. */
 int pigs_swap_tails(pigs_ctx *ctx, int32_t walker, int32_t iw, int32_t ik);
 
+/* ---- K6: device-resident sampler (diagonal sector, sampling='bis'; reference vpi.f90:297-439
+ * with the movers TranslateChain, MoveHeadBisection, MoveTailBisection, Bisection of vpi_mod.f90).
+ * One launch advances EVERY resident walker by one MC step with no host round trip: random
+ * numbers (each walker's own MT19937 stream, identical to the reference's for its seed),
+ * proposals, Delta S, Metropolis and commit all run on the GPU.  The worm sector is not sampled
+ * here: with CWorm = 0 the reference's never-accepted open attempt (quirk Q11) is drawn so that the
+ * stream stays aligned; CWorm > 0 runs use the host-driven sampler. */
+typedef struct pigs_sweep_params {
+    int32_t Nlev, Nstag, CMFreq, Lstag;   /* namelist samp: bisection level, repetitions, CM period, Lstag */
+    double  delta_cm;                     /* effective CM step (vpi.f90:93/123 scaling already applied)      */
+} pigs_sweep_params;
+int pigs_sampler_init(pigs_ctx *ctx, const pigs_sweep_params *sp);
+/* seed walker's stream as the reference's sgrnd(seed) does */
+int pigs_sampler_seed(pigs_ctx *ctx, int32_t walker, int32_t seed);
+/* continue from a generator state in the reference's block form (mti, mt(0:623)) */
+int pigs_sampler_set_rng(pigs_ctx *ctx, int32_t walker, int32_t mti, const int32_t mt[624]);
+/* one MC step (istep is the 1-based step number: CM moves when mod(istep,CMFreq)==0); asynchronous */
+int pigs_sampler_step(pigs_ctx *ctx, int32_t istep);
+/* accepted-move counters per walker since pigs_sampler_init: acc[4*w+{0,1,2,3}] = CM, head, tail, bisection */
+int pigs_sampler_counters(pigs_ctx *ctx, int64_t *acc);
+/* slice ib of every walker in the reference layout R(dim,Np,n_walkers) (for host-side g(r), S(k)) */
+int pigs_slice_download(pigs_ctx *ctx, int32_t ib, double *R);
+
 /* ---- K2/K3: estimator-side sums --------------------------------------------------- */
 /* PotentialEnergy (sample_mod.f90:13-150) on one resident slice (test hook). */
 int pigs_potential_energy_slice(pigs_ctx *ctx, int32_t walker, int32_t ib, int32_t want_F2,

@@ -34,11 +34,18 @@ ABI_SYMBOLS = [
     "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
     "pigs_set_tuning", "pigs_selftest_fastmath",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
+    "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_step",
+    "pigs_sampler_counters", "pigs_slice_download",
 ]
 
 
 class PigsError(RuntimeError):
     pass
+
+
+class PigsSweepParams(C.Structure):
+    _fields_ = [("Nlev", C.c_int32), ("Nstag", C.c_int32), ("CMFreq", C.c_int32), ("Lstag", C.c_int32),
+                ("delta_cm", C.c_double)]
 
 
 class PigsParams(C.Structure):
@@ -90,6 +97,12 @@ def load_library(path=LIB_PATH):
     L.pigs_delta_action_staged.argtypes = [vp, C.c_int64]
     L.pigs_commit_reserve.argtypes = [vp, C.c_int64, C.c_int64] + [C.POINTER(_ip)] * 3 + [C.POINTER(_dp)]
     L.pigs_commit_staged.argtypes = [vp, C.c_int64]
+    L.pigs_sampler_init.argtypes = [vp, C.POINTER(PigsSweepParams)]
+    L.pigs_sampler_seed.argtypes = [vp, C.c_int32, C.c_int32]
+    L.pigs_sampler_set_rng.argtypes = [vp, C.c_int32, C.c_int32, _ip]
+    L.pigs_sampler_step.argtypes = [vp, C.c_int32]
+    L.pigs_sampler_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     for name in ABI_SYMBOLS:
@@ -272,6 +285,35 @@ class PigsContext:
         """Device-pointer form (ints = raw device addresses), asynchronous on the context stream."""
         _chk(self.L, self.L.pigs_delta_action_batch_dev(self.h, int(n), d_walker, d_ip, d_ib, d_xnew,
                                                         d_xold, d_out), "pigs_delta_action_batch_dev")
+
+    # ---- K6: device-resident sampler
+    def sampler_init(self, Nlev=None, Nstag=None, CMFreq=None, Lstag=None, delta_cm=None):
+        c = self.cfg
+        sp = PigsSweepParams(c.Nlev if Nlev is None else Nlev, c.Nstag if Nstag is None else Nstag,
+                             c.CMFreq if CMFreq is None else CMFreq, c.Lstag if Lstag is None else Lstag,
+                             c.delta_cm_eff if delta_cm is None else delta_cm)
+        _chk(self.L, self.L.pigs_sampler_init(self.h, C.byref(sp)), "pigs_sampler_init")
+
+    def sampler_seed(self, walker, seed):
+        _chk(self.L, self.L.pigs_sampler_seed(self.h, int(walker), int(seed)), "pigs_sampler_seed")
+
+    def sampler_set_rng(self, walker, mti, mt):
+        mt = np.ascontiguousarray(mt, np.uint32).view(np.int32)
+        _chk(self.L, self.L.pigs_sampler_set_rng(self.h, int(walker), int(mti), _i(mt)), "pigs_sampler_set_rng")
+
+    def sampler_step(self, istep):
+        _chk(self.L, self.L.pigs_sampler_step(self.h, int(istep)), "pigs_sampler_step")
+
+    def sampler_counters(self):
+        acc = np.zeros((self.n_walkers, 4), np.int64)
+        _chk(self.L, self.L.pigs_sampler_counters(self.h, acc.ctypes.data_as(C.POINTER(C.c_int64))),
+             "pigs_sampler_counters")
+        return acc
+
+    def slice_download(self, ib):
+        R = np.empty((self.n_walkers, self.cfg.Np, self.cfg.dim))
+        _chk(self.L, self.L.pigs_slice_download(self.h, int(ib), _d(R)), "pigs_slice_download")
+        return R
 
     # ---- K5
     def commit_beads(self, walker, ip, ib, x):

@@ -95,6 +95,12 @@ struct pigs_ctx {
     PinBuf      st_w, st_ip, st_ib, st_xn, st_xo, st_out;      // staged items
     PinBuf      cs_w, cs_ip, cs_ib, cs_x;                      // staged commits
     int64_t     st_cap = 0, cs_cap = 0;
+    // device-resident sampler
+    uint32_t   *d_rng = nullptr;
+    unsigned long long *d_counters = nullptr;
+    SweepParams sweep{};
+    int         cm_freq = 1;
+    bool        sampler_ready = false;
 };
 
 static int check_ctx(pigs_ctx *c)
@@ -193,6 +199,8 @@ int pigs_ctx_destroy(pigs_ctx *c)
     c->d_stage.release(); c->d_slices.release(); c->d_res.release();
     c->st_w.release(); c->st_ip.release(); c->st_ib.release(); c->st_xn.release(); c->st_xo.release(); c->st_out.release();
     c->cs_w.release(); c->cs_ip.release(); c->cs_ib.release(); c->cs_x.release();
+    if (c->d_rng) (void)hipFree(c->d_rng);
+    if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_VT) (void)hipFree(c->d_VT);
     if (c->d_WF) (void)hipFree(c->d_WF);
@@ -446,6 +454,103 @@ int pigs_swap_tails(pigs_ctx *c, int32_t walker, int32_t iw, int32_t ik)
         return fail(PIGS_ERR_ARG, "swap_tails(walker=%d, iw=%d, ik=%d) out of range", walker, iw, ik);
     if (iw == ik) return PIGS_OK;
     HIPCHK(launch_swap_tails(c->P, c->d_paths, walker, iw, ik, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+// ---- K6: device-resident sampler ----------------------------------------------------------------
+namespace {
+// reference random_mod.f90:5-31 (seeding) and the conversion of a block-form state (mti, mt) to
+// the sliding form the kernel keeps: the first `mti` steps of the block twist are applied, so slot
+// k < mti already holds element k+624 and the next output is slot mti.
+void mt_seed_words(uint32_t seed, uint32_t *w)
+{
+    w[0] = seed;
+    for (int i = 1; i < 624; ++i) w[i] = 69069u * w[i - 1];
+}
+void mt_block_to_sliding(int mti, uint32_t *w, uint32_t *pos_out)
+{
+    const int n = mti > 624 ? 624 : mti;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t y = (w[i] & 0x80000000u) | (w[(i + 1) % 624] & 0x7fffffffu);
+        w[i] = w[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    *pos_out = (uint32_t)(n % 624);
+}
+} // namespace
+
+int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!sp) return fail(PIGS_ERR_ARG, "null sweep params");
+    if (sp->Nlev < 1 || (1 << sp->Nlev) > 16 || (1 << sp->Nlev) > 2 * c->P.Nb || sp->Nstag < 0 || sp->CMFreq < 1 ||
+        sp->Lstag < 2 || sp->Lstag > c->P.Nb)
+        return fail(PIGS_ERR_ARG, "sweep params out of range (Nlev=%d Nstag=%d CMFreq=%d Lstag=%d)", sp->Nlev, sp->Nstag, sp->CMFreq, sp->Lstag);
+    c->sweep.Nlev = sp->Nlev; c->sweep.Nstag = sp->Nstag; c->sweep.Lstag = sp->Lstag;
+    c->sweep.delta_cm = sp->delta_cm; c->sweep.open_attempt = 1; c->sweep.do_cm = 1;
+    c->cm_freq = sp->CMFreq;
+    if (sweep_lds_bytes(c->P, c->sweep) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
+    if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * 625 * sizeof(uint32_t)));
+    if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, (size_t)c->n_walkers * 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, (size_t)c->n_walkers * 4 * sizeof(unsigned long long), c->stream));
+    std::vector<uint32_t> st((size_t)c->n_walkers * 625);
+    for (int w = 0; w < c->n_walkers; ++w) {
+        mt_seed_words(4357u, &st[(size_t)w * 625]);
+        mt_block_to_sliding(624, &st[(size_t)w * 625], &st[(size_t)w * 625 + 624]);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->sampler_ready = true;
+    return PIGS_OK;
+}
+
+int pigs_sampler_set_rng(pigs_ctx *c, int32_t walker, int32_t mti, const int32_t mt[624])
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
+    if (walker < 0 || walker >= c->n_walkers || !mt || mti < 0 || mti > 624) return fail(PIGS_ERR_ARG, "bad rng state");
+    uint32_t st[625];
+    memcpy(st, mt, 624 * sizeof(uint32_t));
+    mt_block_to_sliding(mti, st, &st[624]);
+    HIPCHK(hipMemcpyAsync(c->d_rng + (size_t)walker * 625, st, sizeof st, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_seed(pigs_ctx *c, int32_t walker, int32_t seed)
+{
+    uint32_t w[624];
+    mt_seed_words((uint32_t)seed, w);
+    return pigs_sampler_set_rng(c, walker, 624, (const int32_t *)w);
+}
+
+int pigs_sampler_step(pigs_ctx *c, int32_t istep)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
+    SweepParams sp = c->sweep;
+    sp.do_cm = (istep % c->cm_freq) == 0;
+    HIPCHK(launch_sweep(c->P, sp, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters, c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_counters(pigs_ctx *c, int64_t *acc)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !acc) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    HIPCHK(hipMemcpyAsync(acc, c->d_counters, (size_t)c->n_walkers * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!R || ib < 0 || ib >= c->P.M) return fail(PIGS_ERR_ARG, "bad slice request");
+    const size_t n = (size_t)c->P.dim * c->P.Np * c->n_walkers;
+    HIPCHK(c->d_stage.reserve(n));
+    HIPCHK(launch_slice_gather(c->P, c->d_paths, ib, c->d_stage.p, c->stream));
+    HIPCHK(hipMemcpyAsync(R, c->d_stage.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PIGS_OK;
 }

@@ -19,6 +19,7 @@
 //                  evaluations are outside rcut and would otherwise idle their lanes).
 // Every variant sums bit-identical per-pair terms; only the summation order differs.
 #include "pigs_device.h"
+#include "pigs_k1_device.h"
 #include "pigs_kernels.h"
 
 namespace pigs {
@@ -162,203 +163,6 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 // =====================================================================================
 // K1 v2
 // =====================================================================================
-namespace {
-
-constexpr int kWaveLds = 8 * kRedStride * (int)sizeof(double);   // 4160 B per wave
-
-// bead classes of UpdateAction (vpi_mod.f90:2509-2525): what is accumulated per pair
-enum BeadClass { CLS_EVEN = 0, CLS_ODD = 1, CLS_END = 2 };
-
-// per-lane accumulators of one item
-template <int DIM, int CLS>
-struct Acc {
-    double potN = 0.0, potO = 0.0;
-    double psiN = 0.0, psiO = 0.0;      // CLS_END only
-    double fN[DIM], fO[DIM];            // CLS_ODD only
-    __device__ __forceinline__ Acc()
-    {
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) { fN[k] = 0.0; fO[k] = 0.0; }
-    }
-};
-
-// in-cutoff work of ONE distance: table cell, V (opt 0), dV/dr (opt 1) and the force terms
-// (dv*xij(k))/rij on odd beads, u (opt 0 of LogWF) on end beads.
-template <int DIM, int CLS, bool IS_OLD, typename VTab>
-__device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, const double *__restrict__ WF,
-                                                double r2, const double (&d)[DIM], Acc<DIM, CLS> &A,
-                                                bool pot_on = true)
-{
-    double r, rinv;
-    sqrt_rinv(r2, r, rinv);
-    const FLerp L = flerp_setup(r, P);
-    if (CLS == CLS_ODD) {
-        double v, dv;
-        finterp01(VT, L, P, v, dv);
-        if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double f = div_by(dv * d[k], r, rinv);            // (dv*xij(k))/rij
-            if (IS_OLD) A.fO[k] = A.fO[k] + f; else A.fN[k] = A.fN[k] + f;
-        }
-    } else {
-        if (pot_on) {
-            const double v = finterp0(VT, L, P);
-            if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
-        }
-        if (CLS == CLS_END) {
-            const double u = finterp0(WF, L, P);
-            if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
-        }
-    }
-}
-
-// reduce the class's accumulators over the wave, apply the Chin weight, store
-template <int DIM, int CLS>
-__device__ __forceinline__ void finish_item(const DevParams &P, int lane, int it, int b, const Acc<DIM, CLS> &A,
-                                            double *red, double *__restrict__ out, double *__restrict__ parts)
-{
-    double dPot, dF2 = 0.0, dPsi = 0.0;
-    if (CLS == CLS_ODD) {
-        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
-        const double t = wave_reduce_lds<8>(v, red, lane);
-        double fn2 = 0.0, fo2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double a = read_lane(t, 2 + k);
-            const double c = read_lane(t, 5 + k);
-            fn2 = fn2 + a * a;                                      // vpi_mod.f90:2831-2832
-            fo2 = fo2 + c * c;
-        }
-        dPot = read_lane(t, 0) - read_lane(t, 1);                   // :2838
-        dF2  = fn2 - fo2;                                           // :2835
-    } else if (CLS == CLS_END) {
-        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
-        const double t = wave_reduce_lds<4>(v, red, lane);
-        dPot = read_lane(t, 0) - read_lane(t, 1);
-        dPsi = read_lane(t, 2) - read_lane(t, 3);                   // :2653
-    } else {
-        const double v[2] = {A.potN, A.potO};
-        const double t = wave_reduce_lds<2>(v, red, lane);
-        dPot = read_lane(t, 0) - read_lane(t, 1);
-    }
-    if (lane == 0) {
-        out[it] = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527
-        if (parts) {
-            parts[(size_t)it * 3 + 0] = dPot;
-            parts[(size_t)it * 3 + 1] = dF2;
-            parts[(size_t)it * 3 + 2] = dPsi;
-        }
-    }
-}
-
-// one item, every partner visited by its lane (no compaction)
-template <int DIM, bool TRAP, int CLS, typename VTab>
-__device__ __forceinline__ void item_direct(const DevParams &P, VTab VT, const double *__restrict__ WF,
-                                            const double *__restrict__ S, int p, const double (&xn)[DIM],
-                                            const double (&xo)[DIM], int lane, int it, int b, double *red,
-                                            double *__restrict__ out, double *__restrict__ parts)
-{
-    Acc<DIM, CLS> A;
-    if (TRAP && lane == 0) {                                          // vpi_mod.f90:2688-2695, 2555-2560
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            A.potN = A.potN + trap_pot(0, P.a_ho[k], xn[k]);
-            A.potO = A.potO + trap_pot(0, P.a_ho[k], xo[k]);
-            if (CLS == CLS_ODD) {
-                A.fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
-                A.fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
-            }
-            if (CLS == CLS_END) {
-                A.psiO = A.psiO + trap_psi(0, P.a_ho[k], xo[k]);
-                A.psiN = A.psiN + trap_psi(0, P.a_ho[k], xn[k]);
-            }
-        }
-    }
-    for (int j0 = 0; j0 < P.Np; j0 += kWave) {
-        const int j = j0 + lane;
-        if (j < P.Np && j != p) {                                     // :2699: row ip is never read
-            double dnew[DIM], dold[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                const double rj = S[(size_t)k * P.NpPad + j];
-                dnew[k] = xn[k] - rj;                                 // :2706-2707
-                dold[k] = xo[k] - rj;
-            }
-            double r2n, r2o;
-            if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
-            else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
-            if (TRAP || r2n <= P.rcut2)                               // :2723 (Q5) / :2771
-                pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
-            const bool in_o = r2o <= P.rcut2;                         // :2745 / :2795
-            if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
-            else if (TRAP && CLS == CLS_END)                          // UpdateWf's trap branch has no cutoff
-                pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
-        }
-    }
-    finish_item<DIM, CLS>(P, lane, it, b, A, red, out, parts);
-}
-
-// one item in two passes: (1) all distances + cutoff, in-cutoff (partner, new|old) codes compacted
-// into the wave's LDS list with ballot/mbcnt; (2) dense lanes re-derive their distance and do the
-// expensive part.  PBC only (TRAP has no cutoff on the new distance), Np <= 256.
-template <int DIM, int CLS, typename VTab>
-__device__ __forceinline__ void item_compact(const DevParams &P, VTab VT, const double *__restrict__ WF,
-                                             const double *__restrict__ S, int p, const double (&xn)[DIM],
-                                             const double (&xo)[DIM], int lane, int it, int b,
-                                             unsigned short *codes, double *red,
-                                             double *__restrict__ out, double *__restrict__ parts)
-{
-    Acc<DIM, CLS> A;
-    const int npass = (P.Np + kWave - 1) / kWave;
-    int count = 0;                                                    // wave-uniform
-    for (int m = 0; m < npass; ++m) {
-        const int j = m * kWave + lane;
-        const bool valid = j < P.Np && j != p;
-        double dnew[DIM], dold[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double rj = valid ? S[(size_t)k * P.NpPad + j] : 0.0;
-            dnew[k] = xn[k] - rj;
-            dold[k] = xo[k] - rj;
-        }
-        const double r2n = min_image_fast<DIM>(dnew, P);
-        const double r2o = min_image_fast<DIM>(dold, P);
-        const bool in_n = valid && r2n <= P.rcut2;
-        const bool in_o = valid && r2o <= P.rcut2;
-        const unsigned long long bn = __ballot(in_n);
-        const unsigned long long bo = __ballot(in_o);
-        const int pn = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bn, 0));
-        count += __builtin_popcountll(bn);
-        const int po = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bo, 0));
-        count += __builtin_popcountll(bo);
-        const unsigned short code = (unsigned short)(((m << 1) << 6) | lane);
-        if (in_n) codes[pn] = code;
-        if (in_o) codes[po] = code | (1u << 6);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < count; t0 += kWave) {
-        const int idx = t0 + lane;
-        if (idx < count) {
-            const unsigned c = codes[idx];
-            const bool is_old = (c >> 6) & 1u;
-            const int j = (int)(c >> 7) * kWave + (int)(c & 63u);
-            double d[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) d[k] = (is_old ? xo[k] : xn[k]) - S[(size_t)k * P.NpPad + j];
-            const double r2 = min_image_fast<DIM>(d, P);
-            if (is_old) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2, d, A);
-            else        pair_accumulate<DIM, CLS, false>(P, VT, WF, r2, d, A);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    finish_item<DIM, CLS>(P, lane, it, b, A, red, out, parts);
-}
-
-} // namespace
-
 // LDS layout (dynamic): [VTable copy: Nmax+2 doubles, if LDSTAB][per wave: kWaveLds bytes = reduction
 // scratch (8 x 65 doubles), whose head doubles as the 512 x u16 code list of COMPACT]
 template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK>
@@ -407,14 +211,14 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
         const double *S = paths + ((size_t)w * P.M + b) * sl;
         const bool odd  = (b & 1) != 0;                         // UpdateAction: force term on odd beads
         const bool endb = (b == 0) || (b == 2 * P.Nb);          // UpdateWf only on the two end beads
+        double *o = out + it;
+        double *q = parts ? parts + (size_t)it * 3 : nullptr;
         if (COMPACT && !TRAP) {
-            if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
-            else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
-            else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, it, b, codes, red, out, parts);
+            if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
+            else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
+            else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
         } else {
-            if (odd)       item_direct<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
-            else if (endb) item_direct<DIM, TRAP, CLS_END>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
-            else           item_direct<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, it, b, red, out, parts);
+            item_eval<DIM, TRAP>(P, VT, WF, S, p, b, xn, xo, lane, red, o, q);
         }
     }
 }

@@ -203,6 +203,13 @@ RUNS = {
     # stock vpi.in (N=64, 65 beads, bis, Nlev=4, Nstag=5, worm on), shortened
     "he4_stock_short": dict(dim=3, Np=64, Nb=32, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
                             Nblock=2, Nstep=6, CWorm="0.5d0", Nobdm=10, Npw=0),
+    # pure diagonal PIGS with bisection sampling (CWorm = 0): the device-resident sampler's scope
+    "he4_bis_cworm0_s1982": dict(dim=3, Np=32, Nb=16, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                                 Nblock=3, Nstep=8, CWorm="0.0d0", Nobdm=0, Npw=0),
+    "he4_bis_cworm0_s1983": dict(dim=3, Np=32, Nb=16, seed=1983, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                                 Nblock=3, Nstep=8, CWorm="0.0d0", Nobdm=0, Npw=0),
+    "trap2d_bis_cworm0": dict(dim=2, Np=6, Nb=8, seed=11, trap="T", a_ho="1.0d0 1.3d0", sampling="bis", Lstag=4,
+                              Nlev=2, Nstag=2, Nblock=2, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, dt="1.0d-2"),
     # CWorm = 0 (quirk Q11): an open proposal is generated and always rejected
     "he4_cworm0": dict(dim=2, Np=9, Nb=6, seed=7, density="0.25d0", sampling="sta", Lstag=4, Nlev=2, Nstag=2,
                        Nblock=3, Nstep=20, CWorm="0.0d0", Nobdm=0, Npw=0),

@@ -1,0 +1,93 @@
+"""K6, the device-resident sampler (one launch = one MC step of every walker, no host in the
+loop), against output files of the reference PROGRAM for pure diagonal PIGS runs (CWorm = 0,
+sampling = 'bis'; tests/golden/vpi_runs/*_cworm0*).
+
+What must hold: every walker draws the reference's random stream for its seed and takes the same
+accept/reject decisions, so the final worldline agrees with the reference's to rounding (the
+Box-Muller log() is the device library's: last-bit differences in the Gaussians, nothing else)
+and the block energies agree to 1e-10 relative (files carry 10 digits)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pathintegralgroundstate_amd import SystemConfig
+
+pytestmark = pytest.mark.gpu
+RUNS = os.path.join(GOLDEN, "vpi_runs")
+
+
+def _run_device(gpu_lib, oracle, cfg, seeds, nblock, nstep):
+    from oracle.pyoracle import System
+    S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt, trap=cfg.trap,
+               a_ho=cfg.a_ho, Lbox=cfg.Lbox, rcut=cfg.rcut)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = len(seeds)
+    ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+    ctx.sampler_init()
+    Paths = []
+    for w, seed in enumerate(seeds):
+        P, g = oracle.init_path(S, seed)             # reference init: consumes Np*dim uniforms
+        Paths.append(P)
+        ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+    ctx.upload_all(np.stack(Paths))
+    blocks = np.zeros((W, nblock, 6))
+    for ib in range(nblock):
+        acc = np.zeros((W, 6))
+        for istep in range(1, nstep + 1):
+            ctx.sampler_step(istep)
+            E1, _, _ = ctx.local_energy_batch(0)
+            E2, _, _ = ctx.local_energy_batch(2 * cfg.Nb)
+            Et, Kt, Pt = ctx.therm_energy_batch()
+            E = 0.5 * (E1 + E2)
+            acc += np.stack([E, E - Pt, Pt, Et, Kt, Pt], 1)
+        blocks[:, ib] = acc / np.float32(nstep) / cfg.Np
+    final = ctx.download_all()
+    counters = ctx.sampler_counters()
+    ctx.close()
+    return blocks, final, counters
+
+
+def _cfg(name):
+    txt = open(os.path.join(RUNS, name, "vpi.in")).read()
+    return SystemConfig.from_namelists(txt)
+
+
+@pytest.mark.parametrize("names", [["he4_bis_cworm0_s1982", "he4_bis_cworm0_s1983"], ["trap2d_bis_cworm0"]])
+def test_device_sampler_reproduces_reference_program(gpu_lib, oracle, names):
+    cfg = _cfg(names[0])
+    seeds = [_cfg(n).seed for n in names]
+    blocks, final, counters = _run_device(gpu_lib, oracle, cfg, seeds, cfg.Nblock, cfg.Nstep)
+    for w, n in enumerate(names):
+        src = os.path.join(RUNS, n)
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        L = np.asarray(cfg.Lbox[:cfg.dim])
+        d = final[w] - want
+        if not cfg.trap:
+            d = d - L * np.round(d / L)              # a last-bit difference may sit on either side of the wrap
+        assert np.max(np.abs(d)) < 1e-10, np.max(np.abs(d))
+        e = np.atleast_2d(np.loadtxt(os.path.join(src, "e_vpi.out")))
+        et = np.atleast_2d(np.loadtxt(os.path.join(src, "et_vpi.out")))
+        got = blocks[w]
+        assert np.all(np.abs(got[:, :3] - e[:, 1:4]) <= 1e-10 * np.abs(e[:, 1:4]) + 1.01e-9 * np.abs(e[:, 1:4]))
+        assert np.all(np.abs(got[:, 3:] - et[:, 1:4]) <= 1e-10 * np.abs(et[:, 1:4]) + 1.01e-9 * np.abs(et[:, 1:4]))
+    assert counters.sum() > 0
+
+
+def test_device_sampler_matches_host_sampler_counters(gpu_lib, oracle):
+    """Same run through the host-driven Fortran sampler (bit-exact with the reference): identical
+    acceptance counts, i.e. identical decisions, move by move in aggregate."""
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    host = os.path.join(ROOT, "pathintegralgroundstate_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    name = "he4_bis_cworm0_s1982"
+    cfg = _cfg(name)
+    blocks, final, counters = _run_device(gpu_lib, oracle, cfg, [cfg.seed], cfg.Nblock, cfg.Nstep)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(RUNS, name, "vpi.in")) as fin, open(os.path.join(td, "out.txt"), "w") as fo:
+            subprocess.run([os.path.join(host, "pigs_vpi")], stdin=fin, stdout=fo, cwd=td, check=True, timeout=600)
+        got = np.fromfile(os.path.join(td, "worldlines_final.bin")).reshape(final[0].shape)
+    assert np.max(np.abs(final[0] - got)) < 1e-10
