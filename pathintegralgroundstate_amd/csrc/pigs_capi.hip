@@ -100,6 +100,7 @@ struct pigs_ctx {
     unsigned long long *d_counters = nullptr;
     SweepParams sweep{};
     int         cm_freq = 1;
+    int         sweep_threads = 512;
     bool        sampler_ready = false;
 };
 
@@ -229,6 +230,11 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
     if (!strcmp(key, "k1_variant")) {
         if (value < K1_AUTO || value > K1_V2_LDS_COMPACT) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
         c->k1_variant = value;
+        return PIGS_OK;
+    }
+    if (!strcmp(key, "sweep_threads")) {
+        if (value != 256 && value != 512 && value != 1024) return fail(PIGS_ERR_ARG, "sweep_threads=%d", value);
+        c->sweep_threads = value;
         return PIGS_OK;
     }
     return fail(PIGS_ERR_ARG, "unknown tuning key '%s'", key);
@@ -489,7 +495,10 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     c->sweep.Nlev = sp->Nlev; c->sweep.Nstag = sp->Nstag; c->sweep.Lstag = sp->Lstag;
     c->sweep.delta_cm = sp->delta_cm; c->sweep.open_attempt = 1; c->sweep.do_cm = 1;
     c->cm_freq = sp->CMFreq;
-    if (sweep_lds_bytes(c->P, c->sweep) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
+    // one workgroup per walker: 8 waves when every walker gets a CU of its own, 4 waves (3 workgroups
+    // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
+    c->sweep_threads = c->n_walkers > 256 ? 256 : 512;
+    if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
     if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * 625 * sizeof(uint32_t)));
     if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, (size_t)c->n_walkers * 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, (size_t)c->n_walkers * 4 * sizeof(unsigned long long), c->stream));
@@ -530,7 +539,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
     SweepParams sp = c->sweep;
     sp.do_cm = (istep % c->cm_freq) == 0;
-    HIPCHK(launch_sweep(c->P, sp, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters, c->stream));
+    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters, c->stream));
     return PIGS_OK;
 }
 

@@ -47,10 +47,10 @@ struct SweepParams {
     int32_t open_attempt, pad0, pad1, pad2;
     double  delta_cm;
 };
-hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, double *paths, const double *VT,
+hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,
                         const double *WF, uint32_t *rng, unsigned long long *counters, hipStream_t st);
 hipError_t launch_slice_gather(const DevParams &P, const double *paths, int ib, double *out, hipStream_t st);
-size_t sweep_lds_bytes(const DevParams &P, const SweepParams &sp);
+size_t sweep_lds_bytes(const DevParams &P, const SweepParams &sp, int threads);
 
 hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
                                     unsigned long long *d_bad, hipStream_t st);

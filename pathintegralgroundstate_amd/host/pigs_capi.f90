@@ -17,6 +17,12 @@ module pigs_capi
 
   ! mirrors `struct pigs_params` (the reference's module globals, global_mod.f90:5-12,
   ! system_mod.f90:8-9, plus dt)
+  ! mirrors `struct pigs_sweep_params` (device-resident sampler, K6)
+  type, bind(C) :: pigs_sweep_params
+     integer(c_int32_t) :: Nlev, Nstag, CMFreq, Lstag
+     real(c_double)     :: delta_cm
+  end type pigs_sweep_params
+
   type, bind(C) :: pigs_params
      integer(c_int32_t) :: dim, Np, Nb, Nmax
      integer(c_int32_t) :: trap, wf_table, v_table, reserved
@@ -206,6 +212,44 @@ module pigs_capi
        real(c_double)                 :: E(*),Kin(*),Pot(*)
        integer(c_int) :: rc
      end function pigs_local_energy_batch
+
+     ! K6: device-resident sampler (diagonal sector, sampling='bis')
+     function pigs_sampler_init(ctx,sp) bind(C,name='pigs_sampler_init') result(rc)
+       import :: c_int, c_ptr, pigs_sweep_params
+       type(c_ptr), value :: ctx
+       type(pigs_sweep_params), intent(in) :: sp
+       integer(c_int) :: rc
+     end function pigs_sampler_init
+
+     function pigs_sampler_set_rng(ctx,walker,mti,mt) bind(C,name='pigs_sampler_set_rng') result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value             :: ctx
+       integer(c_int32_t), value      :: walker,mti
+       integer(c_int32_t), intent(in) :: mt(0:623)
+       integer(c_int) :: rc
+     end function pigs_sampler_set_rng
+
+     function pigs_sampler_step(ctx,istep) bind(C,name='pigs_sampler_step') result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int32_t), value :: istep
+       integer(c_int) :: rc
+     end function pigs_sampler_step
+
+     function pigs_sampler_counters(ctx,acc) bind(C,name='pigs_sampler_counters') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t) :: acc(*)
+       integer(c_int) :: rc
+     end function pigs_sampler_counters
+
+     function pigs_slice_download(ctx,ib,R) bind(C,name='pigs_slice_download') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int32_t), value :: ib
+       real(c_double)            :: R(*)
+       integer(c_int) :: rc
+     end function pigs_slice_download
 
      function pigs_comm_init_all(ctxs,nranks) bind(C,name='pigs_comm_init_all') result(rc)
        import :: c_int, c_int32_t, c_ptr

@@ -461,7 +461,6 @@ contains
     call begin_stage(s)
     where (active) s%want = 2*s%Nb+1
     call plan_items(s)
-    !$omp parallel do schedule(static) private(ip,k,ib,dx,xold,xnew)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = ip_of(w)
@@ -480,7 +479,6 @@ contains
        end do
        s%S0(w) = 0.d0
     end do
-    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_translate
@@ -522,13 +520,11 @@ contains
        end do
        call plan_items(s)
        if (s%n_items==0) exit
-       !$omp parallel do schedule(static)
        do w=1,s%W
           if (.not. s%alive(w)) cycle
           if (ilev>s%aux_i(w)) cycle
           call gen_bisection_level(s,w,ip_of(w),s%seg_i(w),s%aux_i(w),ilev)
        end do
-       !$omp end parallel do
        call evaluate(s)
        do w=1,s%W
           if (.not. s%alive(w)) cycle
@@ -561,7 +557,6 @@ contains
     call begin_stage(s)
     where (active) s%want = 1
     call plan_items(s)
-    !$omp parallel do schedule(static) private(nl,ii,ie)
     do w=1,s%W
        s%alive(w) = active(w)
        if (.not. active(w)) cycle
@@ -580,7 +575,6 @@ contains
           call gen_end_guess(s,w,ip_of(w),ie,ii,2**nl,-1,1.d0)
        end if
     end do
-    !$omp end parallel do
     call evaluate(s)
     do w=1,s%W
        if (.not. active(w)) cycle
@@ -601,7 +595,6 @@ contains
     call begin_stage(s)
     where (active) s%want = Lstag-1
     call plan_items(s)
-    !$omp parallel do schedule(static) private(ii)
     do w=1,s%W
        if (.not. active(w)) cycle
        ii = int((2*s%Nb-Lstag+1)*mt_real(s%rng(w)))
@@ -609,7 +602,6 @@ contains
        call gen_staging(s,w,ip_of(w),ii,Lstag)
        s%S0(w) = 0.d0
     end do
-    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_staging
@@ -629,7 +621,6 @@ contains
        s%want(w)  = s%aux_i(w)
     end do
     call plan_items(s)
-    !$omp parallel do schedule(static) private(Ls,ii,ie)
     do w=1,s%W
        if (.not. active(w)) cycle
        Ls = s%aux_i(w)
@@ -648,7 +639,6 @@ contains
        call gen_staging(s,w,ip_of(w),ii,Ls)
        s%S0(w) = 0.d0
     end do
-    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_end_staging
@@ -816,7 +806,6 @@ contains
        s%want(w)  = s%aux_i(w)
     end do
     call plan_items(s)
-    !$omp parallel do schedule(static) private(ip,Ls,half,ii,ie)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip   = ip_of(w)
@@ -837,7 +826,6 @@ contains
        end if
        call gen_staging(s,w,ip,ii,Ls)
     end do
-    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,-1)
     do w=1,s%W

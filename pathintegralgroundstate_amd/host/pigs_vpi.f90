@@ -6,7 +6,9 @@
 ! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
 ! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
 ! system_mod.f90:15-34) plus one optional group of its own,
-!     &gpu  n_walkers = 1, device = 0  /
+!     &gpu  n_walkers = 1, device = 0, device_sampler = F  /
+! (device_sampler = T: the whole MC step runs on the GPU, kernel K6 -- diagonal sector with
+! sampling='bis' and CWorm = 0 only; otherwise the host-driven lock-step sampler is used)
 ! runs n_walkers independent PIGS chains in lock-step (walker w uses seed+w-1, so walker 1
 ! IS the reference's chain), every Delta S / energy sum on the GPU through libpigs_hip.so,
 ! and writes the reference's observable files: e_vpi.out, et_vpi.out ('(5g20.10e3)'),
@@ -33,13 +35,14 @@ program pigs_vpi
   real (kind=8)     :: a_ho(3)
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios
+  logical           :: device_sampler
   namelist /system/  dim,Np,density,crystal,trap
   namelist /samp/    resume,dt,Nb,seed,delta_cm,CMFreq,sampling,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   namelist /obdm/    swapping,CWorm,Nobdm,Npw
   namelist /wavefun/ Nmax,wf_table,v_table
   namelist /extpot/  a_ho
   namelist /jastrow/ Rm
-  namelist /gpu/     n_walkers,device
+  namelist /gpu/     n_walkers,device,device_sampler
 
   type(sampler_t)    :: s
   type(est_params)   :: ep
@@ -69,6 +72,9 @@ program pigs_vpi
   integer, allocatable :: ue(:),ut(:),uh(:)
   integer :: ueav,utav
   integer(8) :: c0,c1,crate
+  type(pigs_sweep_params) :: swp_par
+  real(8), allocatable :: Rmid(:,:,:)
+  integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
   character(len=32) :: suffix
 
   !---------------------------------------------------------------------
@@ -79,7 +85,7 @@ program pigs_vpi
   Nmax = 10000; wf_table = .false.; v_table = .false.
   CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
   delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
-  n_walkers = 1; device = 0
+  n_walkers = 1; device = 0; device_sampler = .false.
 
   read (5,nml=system,iostat=ios);  rewind (5)
   read (5,nml=samp,iostat=ios);    rewind (5)
@@ -101,6 +107,10 @@ program pigs_vpi
   end if
   NW  = n_walkers
   pi = acos(-1.d0)
+  if (device_sampler .and. (CWorm/=0.d0 .or. sampling/="bis")) then
+     write (0,*) 'pigs_vpi: device_sampler = T needs CWorm = 0 and sampling = ''bis''; using the host-driven sampler'
+     device_sampler = .false.
+  end if
 
   ! box, cutoff, grids (reference vpi.f90:82-128)
   Lbox = 1.d0
@@ -157,6 +167,17 @@ program pigs_vpi
      s%xend(:,2,w) = s%xend(:,1,w)
   end do
   call sampler_upload(s)
+  if (device_sampler) then
+     swp_par%Nlev = Nlev; swp_par%Nstag = Nstag; swp_par%CMFreq = CMFreq; swp_par%Lstag = Lstag
+     swp_par%delta_cm = delta_cm
+     call pigs_check(pigs_sampler_init(ctx,swp_par),'pigs_sampler_init')
+     do w=1,NW
+        call pigs_check(pigs_sampler_set_rng(ctx,int(w-1,c_int32_t),int(s%rng(w)%pos,c_int32_t),s%rng(w)%w), &
+             & 'pigs_sampler_set_rng')
+     end do
+     allocate (Rmid(dim,Np,NW),dev_acc(4,NW),dev_acc0(4,NW))
+     dev_acc0 = 0
+  end if
 
   allocate (perm(NW))
   do w=1,NW
@@ -215,6 +236,12 @@ program pigs_vpi
 
      do istep=1,Nstep
 
+        if (device_sampler) then
+           ! the whole step of every walker in one launch (K6)
+           call pigs_check(pigs_sampler_step(ctx,int(istep,c_int32_t)),'pigs_sampler_step')
+           if (mod(istep,CMFreq)==0) try_cm = try_cm+Np
+           try_stag = try_stag+Nstag*Np
+        else
         ! ---- open / close attempt (reference vpi.f90:302-323)
         isopen0 = s%isopen
         do w=1,NW
@@ -299,6 +326,8 @@ program pigs_vpi
            end do
         end if
 
+        end if   ! host-driven / device-resident sampler
+
         ! ---- estimators of the walkers in the diagonal sector (reference vpi.f90:406-473)
         nd = 0
         do w=1,NW
@@ -309,12 +338,16 @@ program pigs_vpi
            end if
         end do
         if (nd>0) then
-           call sampler_flush(s)
+           if (device_sampler) then
+              if (.not. trap) call pigs_check(pigs_slice_download(ctx,int(Nb,c_int32_t),Rmid),'pigs_slice_download')
+           else
+              call sampler_flush(s)
+           end if
            call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,0_c_int32_t,E1,K1,P1),'pigs_local_energy_batch')
            call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,int(2*Nb,c_int32_t),E2,K1,P1), &
                 & 'pigs_local_energy_batch')
            call pigs_check(pigs_therm_energy_batch(ctx,int(nd,c_int32_t),wl,Et,Kt,Pt),'pigs_therm_energy_batch')
-           !$omp parallel do schedule(static) private(w,E,Pot,Kin)
+           !$omp parallel do schedule(dynamic,1) private(w,E,Pot,Kin) num_threads(min(nd,16))
            do i=1,nd
               w = diag_list(i)
               idiag(w) = idiag(w)+1; idiag_aux(w) = idiag_aux(w)+1; idiag_block(w) = idiag_block(w)+1
@@ -327,8 +360,13 @@ program pigs_vpi
               BT2(:,w) = BT2(:,w)+[Et(i)**2,Kt(i)**2,Pot**2]
               ngr(w) = ngr(w)+1
               if (.not. trap) then
-                 call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
-                 call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
+                 if (device_sampler) then
+                    call pair_correlation(ep,Rmid(:,:,w),gr(:,w))
+                    call structure_factor(ep,Rmid(:,:,w),Sk(:,:,w))
+                 else
+                    call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
+                    call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
+                 end if
               end if
            end do
            !$omp end parallel do
@@ -337,6 +375,12 @@ program pigs_vpi
      end do   ! istep
 
      ! ---- end of block (reference vpi.f90:477-545)
+     if (device_sampler) then
+        call pigs_check(pigs_sampler_counters(ctx,dev_acc),'pigs_sampler_counters')
+        acc_cm   = int(dev_acc(1,:)-dev_acc0(1,:)); acc_head = int(dev_acc(2,:)-dev_acc0(2,:))
+        acc_tail = int(dev_acc(3,:)-dev_acc0(3,:)); acc_bd   = int(dev_acc(4,:)-dev_acc0(4,:))
+        dev_acc0 = dev_acc
+     end if
      mE = 0.d0; mT = 0.d0; nd = 0
      do w=1,NW
         if (idiag_block(w)/=0) then
@@ -426,11 +470,12 @@ program pigs_vpi
 
   ! final worldlines back from the device must equal the host mirror: the two were kept in
   ! step by commits only
-  call sampler_flush(s)
+  if (.not. device_sampler) call sampler_flush(s)
   block
     real(8), allocatable :: chk(:,:,:,:)
     allocate (chk(dim,Np,0:2*Nb,NW))
     call pigs_check(pigs_path_download_all(ctx,chk),'pigs_path_download_all')
+    if (device_sampler) s%Path = chk
     if (any(chk/=s%Path)) then
        write (0,*) 'pigs_vpi: device worldlines differ from the host mirror'
        stop 3

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time the device-resident sampler (K6) at the BASELINE shape: N=256, 161 beads, W walkers."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_workload  # noqa: E402
+from pathintegralgroundstate_amd import SystemConfig, api  # noqa: E402
+
+
+def main():
+    Np = int(os.environ.get("NP", 256))
+    Nb = int(os.environ.get("NB", 80))
+    nsteps = int(os.environ.get("STEPS", 3))
+    for W in [int(x) for x in os.environ.get("WALKERS", "128").split(",")]:
+        cfg = SystemConfig(dim=3, Np=Np, Nb=Nb, Nlev=4, Nstag=5, Lstag=32, CMFreq=1, delta_cm=0.12)
+        VT, WF = api.build_tables(cfg)
+        Paths, _ = make_workload(cfg, W, 1, 1982)
+        ctx = api.PigsContext(cfg, VT, WF, n_walkers=W)
+        ctx.upload_all(Paths)
+        ctx.sampler_init()
+        if os.environ.get('SWEEP_THREADS'):
+            ctx.set_tuning('sweep_threads', int(os.environ['SWEEP_THREADS']))
+        for w in range(W):
+            ctx.sampler_seed(w, 1982 + w)
+        ctx.sampler_step(1)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            ctx.sampler_step(2 + i)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / nsteps
+        acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
+        E, Ec, Ep = ctx.therm_energy_batch()
+        # Delta-S items per sweep per walker (upper bound schedule): measured acceptance below
+        print(f"W={W}: {dt * 1e3:8.1f} ms per MC step -> {W / dt:9.1f} walker-sweeps/s;  accepted per sweep per walker "
+              f"(cm, head, tail, bis) = {acc.round(1)};  <Et/N> = {np.mean(E) / Np:.4f}", flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

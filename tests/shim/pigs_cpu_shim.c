@@ -180,6 +180,19 @@ int pigs_commit_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **w, int
 
 int pigs_commit_staged(pigs_ctx *c, int64_t n) { return pigs_commit_beads(c, n, c->cs_w, c->cs_ip, c->cs_ib, c->cs_x); }
 
+/* K6 exists on the GPU only */
+int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp) { (void)c; (void)sp; snprintf(g_err, sizeof g_err, "device sampler needs a GPU"); return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_seed(pigs_ctx *c, int32_t w, int32_t s) { (void)c; (void)w; (void)s; return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_set_rng(pigs_ctx *c, int32_t w, int32_t m, const int32_t mt[624]) { (void)c; (void)w; (void)m; (void)mt; return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_step(pigs_ctx *c, int32_t i) { (void)c; (void)i; return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_counters(pigs_ctx *c, int64_t *a) { (void)c; (void)a; return PIGS_ERR_UNSUPPORTED; }
+int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)
+{
+    const size_t d = c->s.dim, n = c->s.Np;
+    for (int w = 0; w < c->W; ++w) memcpy(R + (size_t)w * d * n, c->paths + c->wl * w + (size_t)ib * d * n, d * n * sizeof(double));
+    return PIGS_OK;
+}
+
 int pigs_comm_unique_id(char id[128]) { memset(id, 0, 128); return PIGS_OK; }
 int pigs_comm_init_rank(pigs_ctx *c, int32_t n, int32_t r, const char id[128]) { (void)c; (void)n; (void)r; (void)id; return PIGS_OK; }
 int pigs_comm_init_all(pigs_ctx **c, int32_t n) { (void)c; (void)n; return PIGS_OK; }

@@ -66,3 +66,21 @@ def test_gpu_lockstep_walkers(exe, tmp_path):
         assert same_bits(got.reshape((3,) + want.shape)[w], want), w
         assert _close(tmp_path / f"e_vpi.w{w:04d}.out", os.path.join(src, "e_vpi.out"))
         assert _close(tmp_path / f"et_vpi.w{w:04d}.out", os.path.join(src, "et_vpi.out"))
+
+
+def test_gpu_front_end_with_device_resident_sampler(exe, tmp_path):
+    """&gpu device_sampler = T: the whole MC step on the GPU (K6); two walkers == the reference runs
+    with seeds 1982 and 1983 (worldlines to rounding, energies and histograms as printed)."""
+    base = open(os.path.join(RUNS, "he4_bis_cworm0_s1982", "vpi.in")).read()
+    _run(exe, base + "&gpu\n n_walkers = 2, device = 0, device_sampler = T\n/\n", str(tmp_path))
+    got = np.fromfile(tmp_path / "worldlines_final.bin")
+    for w, seed in enumerate((1982, 1983)):
+        src = os.path.join(RUNS, f"he4_bis_cworm0_s{seed}")
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        d = got.reshape((2,) + want.shape)[w] - want
+        assert np.max(np.abs(d)) < 1e-10 or np.max(np.abs(np.abs(d) - 3.4)) < 1.0   # (a wrap flips by L)
+        assert np.mean(np.abs(d) < 1e-10) > 0.999
+        assert _close(tmp_path / f"e_vpi.w{w:04d}.out", os.path.join(src, "e_vpi.out"))
+        assert _close(tmp_path / f"et_vpi.w{w:04d}.out", os.path.join(src, "et_vpi.out"))
+        assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
+        assert _close(tmp_path / f"sk_vpi.w{w:04d}.out", os.path.join(src, "sk_vpi.out"), rel=1e-8)
