@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--nb", type=int, default=80, help="reference namelist Nb (beads = 2*Nb+1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--variant", type=int, default=0, help="K1 kernel variant (0 = library default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse "
+                                                      "the multi-process path on a one-GPU machine)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +128,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.same_device:
+            local = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, (world, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -173,15 +181,19 @@ def main():
     ev1.record(kstream)
     ctx.sync()
     if world > 1:
-        dist.all_reduce(est)                                    # RCCL, once per block
+        if args.backend == "nccl":
+            dist.all_reduce(est)                                # RCCL over xGMI, once per block
+        else:
+            est_h = est.cpu(); dist.all_reduce(est_h); est.copy_(est_h)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -200,12 +212,48 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # ---- second half of BASELINE's metric: MC sweeps / s.  The device-resident sampler (K6) advances
+    # every resident walker by whole MC steps (CM move of every particle + Nstag x Np x {head, tail,
+    # bisection}, stock vpi.in schedule CMFreq=1 Nstag=5 Nlev=4) with no host in the loop.
+    mc = None
+    try:
+        mcfg = SystemConfig(dim=3, Np=args.np, Nb=args.nb, density=0.365, dt=5e-3, Rm=1.2, Nlev=4, Nstag=5,
+                            Lstag=32, CMFreq=1, delta_cm=0.12)
+        ctx.sampler_init(Nlev=mcfg.Nlev, Nstag=mcfg.Nstag, CMFreq=1, Lstag=min(32, args.nb), delta_cm=mcfg.delta_cm_eff)
+        for w in range(W):
+            ctx.sampler_seed(w, 1982 + rank * W + w)
+        acc0 = ctx.sampler_counters()
+        ctx.sampler_step(1)
+        ctx.sync()
+        nmc = 3
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(nmc):
+            ctx.sampler_step(2 + i)
+        ctx.sync()
+        mc_el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([mc_el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mc_el = float(tt.item())
+        acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 1))
+        # Delta-S items of one sweep of one walker: Np*(2Nb+1) + the bisection stages actually run;
+        # the exact count depends on early exits, so it is bounded by SURVEY 8d's schedule
+        mc = {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc,
+              "walkers_per_gpu": W, "kernel": "pigs::k_sweep (one launch per MC step)",
+              "accepted_moves_per_sweep_per_walker": {"cm": acc[0], "head": acc[1], "tail": acc[2], "bisection": acc[3]},
+              "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in)",
+              "reference_cpu_sweeps_per_s_per_core": 1.24}
+    except api.PigsError as exc:       # pragma: no cover
+        mc = {"error": str(exc)}
+
     # correctness of what was timed: rank 0 checks one stage against the oracle
     got = d_out[0].cpu().numpy()
     result = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:            # cpu_baseline: rank 0 at N=1 only
             cpu, want = cpu_baseline(cfg, VT, WF, Paths, sets)
             # `want` is the oracle's result for the last stage it ran; recompute stage 0 if different
             from oracle.pyoracle import Oracle, System
@@ -232,6 +280,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),
+            "mc": mc,
         }
     ctx.close()
     if world > 1:
