@@ -495,9 +495,9 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     c->sweep.Nlev = sp->Nlev; c->sweep.Nstag = sp->Nstag; c->sweep.Lstag = sp->Lstag;
     c->sweep.delta_cm = sp->delta_cm; c->sweep.open_attempt = 1; c->sweep.do_cm = 1;
     c->cm_freq = sp->CMFreq;
-    // one workgroup per walker: 8 waves when every walker gets a CU of its own, 4 waves (3 workgroups
+    // one workgroup per walker: 16 waves when every walker gets a CU of its own, 4 waves (3 workgroups
     // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
-    c->sweep_threads = c->n_walkers > 256 ? 256 : 512;
+    c->sweep_threads = c->n_walkers > 256 ? 256 : 1024;
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
     if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * 625 * sizeof(uint32_t)));
     if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, (size_t)c->n_walkers * 4 * sizeof(unsigned long long)));

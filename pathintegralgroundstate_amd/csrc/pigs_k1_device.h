@@ -98,6 +98,55 @@ __device__ __forceinline__ void finish_item(const DevParams &P, int lane, int b,
     }
 }
 
+// the reference's one-body terms of a trapped system enter the sums once (vpi_mod.f90:2688-2695,
+// 2555-2560): lane 0 of the wave that owns the item's first pass adds them
+template <int DIM, bool TRAP, int CLS>
+__device__ __forceinline__ void trap_terms(const DevParams &P, const double (&xn)[DIM], const double (&xo)[DIM],
+                                           Acc<DIM, CLS> &A)
+{
+    if (!TRAP) return;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        A.potN = A.potN + trap_pot(0, P.a_ho[k], xn[k]);
+        A.potO = A.potO + trap_pot(0, P.a_ho[k], xo[k]);
+        if (CLS == CLS_ODD) {
+            A.fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
+            A.fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
+        }
+        if (CLS == CLS_END) {
+            A.psiO = A.psiO + trap_psi(0, P.a_ho[k], xo[k]);
+            A.psiN = A.psiN + trap_psi(0, P.a_ho[k], xn[k]);
+        }
+    }
+}
+
+// partner j of the moved particle p: both distances, cutoff tests, accumulate
+template <int DIM, bool TRAP, int CLS, typename VTab>
+__device__ __forceinline__ void partner_accumulate(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                                   const double *__restrict__ S, int p, int j,
+                                                   const double (&xn)[DIM], const double (&xo)[DIM],
+                                                   Acc<DIM, CLS> &A)
+{
+    if (j < P.Np && j != p) {                                         // :2699: row ip is never read
+        double dnew[DIM], dold[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double rj = S[(size_t)k * P.NpPad + j];
+            dnew[k] = xn[k] - rj;                                     // :2706-2707
+            dold[k] = xo[k] - rj;
+        }
+        double r2n, r2o;
+        if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+        else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
+        if (TRAP || r2n <= P.rcut2)                                   // :2723 (Q5) / :2771
+            pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
+        const bool in_o = r2o <= P.rcut2;                             // :2745 / :2795
+        if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
+        else if (TRAP && CLS == CLS_END)                              // UpdateWf's trap branch has no cutoff
+            pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
+    }
+}
+
 // one item, every partner visited by its lane (no compaction)
 template <int DIM, bool TRAP, int CLS, typename VTab>
 __device__ __forceinline__ void item_direct(const DevParams &P, VTab VT, const double *__restrict__ WF,
@@ -106,43 +155,76 @@ __device__ __forceinline__ void item_direct(const DevParams &P, VTab VT, const d
                                             double *out, double *parts)
 {
     Acc<DIM, CLS> A;
-    if (TRAP && lane == 0) {                                          // vpi_mod.f90:2688-2695, 2555-2560
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            A.potN = A.potN + trap_pot(0, P.a_ho[k], xn[k]);
-            A.potO = A.potO + trap_pot(0, P.a_ho[k], xo[k]);
-            if (CLS == CLS_ODD) {
-                A.fO[k] = trap_pot(1, P.a_ho[k], xo[k]);
-                A.fN[k] = trap_pot(1, P.a_ho[k], xn[k]);
-            }
-            if (CLS == CLS_END) {
-                A.psiO = A.psiO + trap_psi(0, P.a_ho[k], xo[k]);
-                A.psiN = A.psiN + trap_psi(0, P.a_ho[k], xn[k]);
-            }
-        }
-    }
-    for (int j0 = 0; j0 < P.Np; j0 += kWave) {
-        const int j = j0 + lane;
-        if (j < P.Np && j != p) {                                     // :2699: row ip is never read
-            double dnew[DIM], dold[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                const double rj = S[(size_t)k * P.NpPad + j];
-                dnew[k] = xn[k] - rj;                                 // :2706-2707
-                dold[k] = xo[k] - rj;
-            }
-            double r2n, r2o;
-            if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
-            else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
-            if (TRAP || r2n <= P.rcut2)                               // :2723 (Q5) / :2771
-                pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
-            const bool in_o = r2o <= P.rcut2;                         // :2745 / :2795
-            if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
-            else if (TRAP && CLS == CLS_END)                          // UpdateWf's trap branch has no cutoff
-                pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
-        }
-    }
+    if (TRAP && lane == 0) trap_terms<DIM, TRAP, CLS>(P, xn, xo, A);
+    for (int j0 = 0; j0 < P.Np; j0 += kWave)
+        partner_accumulate<DIM, TRAP, CLS>(P, VT, WF, S, p, j0 + lane, xn, xo, A);
     finish_item<DIM, CLS>(P, lane, b, A, red, out, parts);
+}
+
+// ---- split form (device-resident sampler, few beads per stage): one wave does ONE pass of 64
+// partners of an item and leaves its 8 wave totals in tot8[]; item_finish_split() adds the passes
+// of an item in pass order and applies the Chin weight.  Totals layout: potN potO fN[3] fO[3]
+// (odd) / potN potO psiN psiO (end) / potN potO (even).
+template <int DIM, bool TRAP, int CLS, typename VTab>
+__device__ __forceinline__ void item_pass_cls(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                              const double *__restrict__ S, int p, int m,
+                                              const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                              double *red, double *tot8)
+{
+    Acc<DIM, CLS> A;
+    if (TRAP && m == 0 && lane == 0) trap_terms<DIM, TRAP, CLS>(P, xn, xo, A);
+    partner_accumulate<DIM, TRAP, CLS>(P, VT, WF, S, p, m * kWave + lane, xn, xo, A);
+    if (CLS == CLS_ODD) {
+        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
+        const double t = wave_reduce_lds<8>(v, red, lane);
+        if (lane < 8) tot8[lane] = t;
+    } else if (CLS == CLS_END) {
+        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
+        const double t = wave_reduce_lds<4>(v, red, lane);
+        if (lane < 4) tot8[lane] = t;
+    } else {
+        const double v[2] = {A.potN, A.potO};
+        const double t = wave_reduce_lds<2>(v, red, lane);
+        if (lane < 2) tot8[lane] = t;
+    }
+}
+
+template <int DIM, bool TRAP, typename VTab>
+__device__ __forceinline__ void item_pass(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                          const double *__restrict__ S, int p, int b, int m,
+                                          const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                          double *red, double *tot8)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       item_pass_cls<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+    else if (endb) item_pass_cls<DIM, TRAP, CLS_END>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+    else           item_pass_cls<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+}
+
+// one thread: Delta S of an item from its npass x 8 wave totals
+template <int DIM>
+__device__ __forceinline__ double item_finish_split(const DevParams &P, int b, int npass, const double *tot)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int nv = odd ? 8 : (endb ? 4 : 2);
+    for (int m = 0; m < npass; ++m)
+        for (int q = 0; q < nv; ++q) s[q] = s[q] + tot[m * 8 + q];
+    double dF2 = 0.0, dPsi = 0.0;
+    const double dPot = s[0] - s[1];
+    if (odd) {
+        double fn2 = 0.0, fo2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { fn2 = fn2 + s[2 + k] * s[2 + k]; fo2 = fo2 + s[5 + k] * s[5 + k]; }
+        dF2 = fn2 - fo2;
+    } else if (endb) {
+        dPsi = s[2] - s[3];
+    }
+    return -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);
 }
 
 // one item in two passes: (1) all distances + cutoff, in-cutoff (partner, new|old) codes compacted

@@ -17,7 +17,8 @@ def main():
     Nb = int(os.environ.get("NB", 80))
     nsteps = int(os.environ.get("STEPS", 3))
     for W in [int(x) for x in os.environ.get("WALKERS", "128").split(",")]:
-        cfg = SystemConfig(dim=3, Np=Np, Nb=Nb, Nlev=4, Nstag=5, Lstag=32, CMFreq=1, delta_cm=0.12)
+        cfg = SystemConfig(dim=3, Np=Np, Nb=Nb, Nlev=int(os.environ.get('NLEV', 4)), Nstag=int(os.environ.get('NSTAG', 5)),
+                           Lstag=32, CMFreq=int(os.environ.get('CMFREQ', 1)), delta_cm=0.12)
         VT, WF = api.build_tables(cfg)
         Paths, _ = make_workload(cfg, W, 1, 1982)
         ctx = api.PigsContext(cfg, VT, WF, n_walkers=W)
@@ -35,7 +36,13 @@ def main():
         ctx.sync()
         dt = (time.perf_counter() - t0) / nsteps
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
+        t1 = time.perf_counter()
         E, Ec, Ep = ctx.therm_energy_batch()
+        t2 = time.perf_counter()
+        ctx.local_energy_batch(0)
+        ctx.local_energy_batch(2 * cfg.Nb)
+        t3 = time.perf_counter()
+        print(f"   estimators for {W} walkers: ThermEnergy {1e3 * (t2 - t1):.1f} ms, 2 x LocalEnergy {1e3 * (t3 - t2):.1f} ms", flush=True)
         # Delta-S items per sweep per walker (upper bound schedule): measured acceptance below
         print(f"W={W}: {dt * 1e3:8.1f} ms per MC step -> {W / dt:9.1f} walker-sweeps/s;  accepted per sweep per walker "
               f"(cm, head, tail, bis) = {acc.round(1)};  <Et/N> = {np.mean(E) / Np:.4f}", flush=True)
