@@ -75,6 +75,15 @@ int pigs_selftest_fastmath(pigs_ctx *ctx, int32_t blocks, int32_t iters, uint64_
  * and the ghost cells.  Arrays hold Nmax+2 doubles. */
 int pigs_build_tables(int32_t Nmax, double Rm, double rmax, double *VTable, double *LogWF,
                       double *dr_out);
+/* Same with a choice of pair potential.  The reference selects its potential by editing
+ * system_mod.f90 and recompiling: kind 0 = Aziz-II HFD-B(HE) (the active code,
+ * system_mod.f90:136-182), 1 = Lennard-Jones V0*(1/r^6-1)/r^6 with V0 = 22.0228 (the commented
+ * block system_mod.f90:70-83; BASELINE config 2), 2 = dipolar 1/r^3 (BASELINE config 5). */
+#define PIGS_POT_AZIZ2 0
+#define PIGS_POT_LJ 1
+#define PIGS_POT_DIPOLAR 2
+int pigs_build_tables_kind(int32_t kind, int32_t Nmax, double Rm, double rmax, double *VTable,
+                           double *LogWF, double *dr_out);
 
 /* ---- worldline residency (replaces the host array Path, vpi.f90:134) ------------ */
 int pigs_path_upload(pigs_ctx *ctx, int32_t walker, const double *Path);

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "pigs_set_tuning", "pigs_selftest_fastmath",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_step",
-    "pigs_sampler_counters", "pigs_slice_download",
+    "pigs_sampler_counters", "pigs_slice_download", "pigs_build_tables_kind",
 ]
 
 
@@ -77,6 +77,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sync.argtypes = [vp]
     L.pigs_stream.argtypes = [vp, C.POINTER(vp)]
     L.pigs_build_tables.argtypes = [C.c_int32, C.c_double, C.c_double, _dp, _dp, _dp]
+    L.pigs_build_tables_kind.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, _dp, _dp, _dp]
     L.pigs_path_upload.argtypes = [vp, C.c_int32, _dp]
     L.pigs_path_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_path_upload_all.argtypes = [vp, _dp]
@@ -141,14 +142,17 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
-def build_tables(cfg: SystemConfig):
+POTENTIALS = {"aziz2": 0, "lj": 1, "dipolar": 2}
+
+
+def build_tables(cfg: SystemConfig, potential="aziz2"):
     """PotentialTable / JastrowTable (reference vpi_mod.f90:84-145) on the host."""
     L = load_library()
     VT = np.zeros(cfg.Nmax + 2)
     WF = np.zeros(cfg.Nmax + 2)
     dr = C.c_double()
-    _chk(L, L.pigs_build_tables(cfg.Nmax, cfg.Rm, cfg.rcut, _d(VT), _d(WF), C.byref(dr)),
-         "pigs_build_tables")
+    _chk(L, L.pigs_build_tables_kind(POTENTIALS[potential], cfg.Nmax, cfg.Rm, cfg.rcut, _d(VT), _d(WF),
+                                     C.byref(dr)), "pigs_build_tables_kind")
     assert dr.value == cfg.dr
     return VT, WF
 

@@ -34,16 +34,32 @@ double mcmillan(double Rm, double r)
     return -0.5 * (q * q * q * q * q);
 }
 
+// Lennard-Jones in units of sigma and hbar^2/(m sigma^2) (reference system_mod.f90:70-83, commented out there)
+double lennard_jones(double r)
+{
+    const double v0 = 22.0228;
+    const double r6 = std::pow(r, 6);
+    return v0 * (1.0 / r6 - 1.0) / r6;
+}
+
+double dipolar(double r) { return 1.0 / (r * r * r); }
+
 } // namespace
 
 extern "C" int pigs_build_tables(int32_t Nmax, double Rm, double rmax, double *VTable, double *LogWF,
                                  double *dr_out)
 {
-    if (Nmax < 4 || !(rmax > 0.0)) return PIGS_ERR_ARG;
+    return pigs_build_tables_kind(PIGS_POT_AZIZ2, Nmax, Rm, rmax, VTable, LogWF, dr_out);
+}
+
+extern "C" int pigs_build_tables_kind(int32_t kind, int32_t Nmax, double Rm, double rmax, double *VTable,
+                                      double *LogWF, double *dr_out)
+{
+    if (Nmax < 4 || !(rmax > 0.0) || kind < 0 || kind > 2) return PIGS_ERR_ARG;
     const double dr = rmax / (double)(float)(Nmax - 1);
     for (int i = 1; i <= Nmax; ++i) {
         const double r = (double)(i - 1) * dr;
-        if (VTable) VTable[i] = aziz2(r);
+        if (VTable) VTable[i] = kind == PIGS_POT_LJ ? lennard_jones(r) : kind == PIGS_POT_DIPOLAR ? dipolar(r) : aziz2(r);
         if (LogWF) LogWF[i] = mcmillan(Rm, r);
     }
     if (VTable) { VTable[0] = VTable[2]; VTable[Nmax + 1] = VTable[Nmax]; }

@@ -81,6 +81,15 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_build_tables
 
+     function pigs_build_tables_kind(kind,Nmax,Rm,rmax,VTable,LogWF,dr_out) &
+          & bind(C,name='pigs_build_tables_kind') result(rc)
+       import :: c_int, c_int32_t, c_double
+       integer(c_int32_t), value :: kind,Nmax
+       real(c_double), value     :: Rm,rmax
+       real(c_double)            :: VTable(*),LogWF(*),dr_out
+       integer(c_int) :: rc
+     end function pigs_build_tables_kind
+
      function pigs_path_upload(ctx,walker,Path) bind(C,name='pigs_path_upload') result(rc)
        import :: c_int, c_int32_t, c_double, c_ptr
        type(c_ptr), value        :: ctx

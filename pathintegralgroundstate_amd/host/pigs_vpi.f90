@@ -6,7 +6,8 @@
 ! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
 ! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
 ! system_mod.f90:15-34) plus one optional group of its own,
-!     &gpu  n_walkers = 1, device = 0, device_sampler = F  /
+!     &gpu  n_walkers = 1, device = 0, device_sampler = F, potential = 'aziz2'  /
+! (potential: aziz2 | lj | dipolar -- the reference selects it by editing system_mod.f90)
 ! (device_sampler = T: the whole MC step runs on the GPU, kernel K6 -- diagonal sector with
 ! sampling='bis' and CWorm = 0 only; otherwise the host-driven lock-step sampler is used)
 ! runs n_walkers independent PIGS chains in lock-step (walker w uses seed+w-1, so walker 1
@@ -36,13 +37,15 @@ program pigs_vpi
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios
   logical           :: device_sampler
+  character (len=8) :: potential
+  integer           :: pot_kind
   namelist /system/  dim,Np,density,crystal,trap
   namelist /samp/    resume,dt,Nb,seed,delta_cm,CMFreq,sampling,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   namelist /obdm/    swapping,CWorm,Nobdm,Npw
   namelist /wavefun/ Nmax,wf_table,v_table
   namelist /extpot/  a_ho
   namelist /jastrow/ Rm
-  namelist /gpu/     n_walkers,device,device_sampler
+  namelist /gpu/     n_walkers,device,device_sampler,potential
 
   type(sampler_t)    :: s
   type(est_params)   :: ep
@@ -85,7 +88,7 @@ program pigs_vpi
   Nmax = 10000; wf_table = .false.; v_table = .false.
   CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
   delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
-  n_walkers = 1; device = 0; device_sampler = .false.
+  n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'
 
   read (5,nml=system,iostat=ios);  rewind (5)
   read (5,nml=samp,iostat=ios);    rewind (5)
@@ -135,7 +138,17 @@ program pigs_vpi
 
   ! tables on the host (reference vpi_mod.f90:84-145), then the GPU context
   allocate (VTable(0:Nmax+1),LogWF(0:Nmax+1))
-  call pigs_check(pigs_build_tables(int(Nmax,c_int32_t),Rm,rcut,VTable,LogWF,dr),'pigs_build_tables')
+  ! the reference picks its pair potential by editing system_mod.f90; here it is an input
+  select case (trim(potential))
+  case ('aziz2');   pot_kind = 0
+  case ('lj');      pot_kind = 1
+  case ('dipolar'); pot_kind = 2
+  case default
+     write (0,*) 'pigs_vpi: unknown potential ',trim(potential),' (aziz2 | lj | dipolar)'
+     stop 2
+  end select
+  call pigs_check(pigs_build_tables_kind(int(pot_kind,c_int32_t),int(Nmax,c_int32_t),Rm,rcut,VTable,LogWF,dr), &
+       & 'pigs_build_tables_kind')
   gp%dim = dim; gp%Np = Np; gp%Nb = Nb; gp%Nmax = Nmax
   gp%trap = merge(1,0,trap); gp%wf_table = 1; gp%v_table = 1; gp%reserved = 0
   gp%dr = dr; gp%rcut2 = rcut2; gp%dt = dt; gp%Rm = Rm

@@ -70,6 +70,20 @@ int pigs_build_tables(int32_t Nmax, double Rm, double rmax, double *VT, double *
     return PIGS_OK;
 }
 
+int pigs_build_tables_kind(int32_t kind, int32_t Nmax, double Rm, double rmax, double *VT, double *WF, double *dr)
+{
+    int rc = pigs_build_tables(Nmax, Rm, rmax, VT, WF, dr);
+    if (kind != 0 && VT) {
+        const double h = po_table_dr(rmax, Nmax);
+        for (int i = 1; i <= Nmax; ++i) {
+            const double r = (double)(i - 1) * h;
+            VT[i] = kind == 1 ? 22.0228 * (1.0 / pow(r, 6) - 1.0) / pow(r, 6) : 1.0 / (r * r * r);
+        }
+        VT[0] = VT[2]; VT[Nmax + 1] = VT[Nmax];
+    }
+    return rc;
+}
+
 int pigs_path_upload(pigs_ctx *c, int32_t w, const double *P) { memcpy(c->paths + c->wl * w, P, c->wl * sizeof(double)); return PIGS_OK; }
 int pigs_path_download(pigs_ctx *c, int32_t w, double *P) { memcpy(P, c->paths + c->wl * w, c->wl * sizeof(double)); return PIGS_OK; }
 int pigs_path_upload_all(pigs_ctx *c, const double *P) { memcpy(c->paths, P, c->wl * c->W * sizeof(double)); return PIGS_OK; }

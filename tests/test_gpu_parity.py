@@ -337,3 +337,63 @@ def test_full_size_properties(gpu_lib, oracle):
     Paths_before = Paths
     want = oracle.delta_action_batch(S, WF, VT, Paths_before, w[sel], ip[sel], ib[sel], xb[sel], xa[sel])
     assert np.all(np.abs(ab[sel] - want) <= 1e-10 * np.abs(want) + 1e-11)
+
+
+def test_rccl_estimator_allreduce_single_rank(gpu_lib):
+    """The RCCL path of pigs_estimators_allreduce (dlopen'ed librccl, communicator of one rank on this
+    one-GPU box): sum over one rank is the identity; a second context gets its own communicator."""
+    import ctypes as C
+    t = load_golden("tables_he4_n64")
+    cfg = config_from_golden(t)
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=1) as ctx:
+        uid = gpu_lib.comm_unique_id()
+        assert len(uid) == 128
+        ctx.comm_init_rank(1, 0, uid)
+        v = np.arange(390, dtype=float) * 0.5 - 7.0
+        out = ctx.estimators_allreduce(v)
+        assert same_bits(out, v)
+        # single-process form used by a Fortran host with one thread per GPU
+        L = gpu_lib.load_library()
+        arr = (C.c_void_p * 1)(ctx.h)
+        assert L.pigs_comm_init_all(arr, 1) == 0
+        assert same_bits(ctx.estimators_allreduce(v), v)
+    # without a communicator the call fails loudly
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=1) as ctx:
+        with pytest.raises(gpu_lib.PigsError, match="communicator"):
+            ctx.estimators_allreduce(np.ones(4))
+
+
+def test_host_pointer_batch_rate_is_reported(gpu_lib):
+    """PCIe-inclusive form (host pointers): only checks that it works at the bench size and prints its
+    rate for DESIGN.md; the bench's `value` is always the resident-input rate."""
+    import time
+    cfg = SystemConfigC3()
+    t = load_golden("tables_he4_n256")
+    W = 16
+    rng = np.random.default_rng(0)
+    L = cfg.Lbox[0]
+    Paths = rng.uniform(-L / 2, L / 2, (W, cfg.M, cfg.Np, 3))
+    w = np.repeat(np.arange(W, dtype=np.int32), cfg.M)
+    ib = np.tile(np.arange(cfg.M, dtype=np.int32), W)
+    ip = np.ones(W * cfg.M, np.int32)
+    xo = Paths[w, ib, 0].copy()
+    xn = xo + 0.01
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        a = ctx.delta_action_batch(w, ip, ib, xn, xo)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            a = ctx.delta_action_batch(w, ip, ib, xn, xo)
+        dt1 = (time.perf_counter() - t0) / 20
+        b = ctx.delta_action_staged(w, ip, ib, xn, xo)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            b = ctx.delta_action_staged(w, ip, ib, xn, xo)
+        dt2 = (time.perf_counter() - t0) / 20
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.all((a == b) | np.isnan(a))
+    print(f"host-pointer batch of {len(w)} items: {dt1 * 1e6:.0f} us (copying form), {dt2 * 1e6:.0f} us (staged form)")
+
+
+def SystemConfigC3():
+    from pathintegralgroundstate_amd import SystemConfig
+    return SystemConfig(dim=3, Np=256, Nb=80)

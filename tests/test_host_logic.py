@@ -138,3 +138,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".f90")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "pyoracle" not in src and "pigs_oracle" not in src and "libvpiref" not in src, f
+
+
+def test_lj_and_dipolar_table_fill():
+    """Host table fill for the potentials of BASELINE configs 2 and 5 against the externally filled
+    tables of the golden fixtures (numpy expressions of the same formulas: <= 4 ulp)."""
+    from pathintegralgroundstate_amd import api
+    from pathintegralgroundstate_amd.build import build
+    build()
+    c = SystemConfig(dim=3, Np=64, Nb=40)
+    for kind in ("lj", "dipolar"):
+        VT, WF = api.build_tables(c, potential=kind)
+        want = load_golden(f"he4_n64_table_{kind}")["VTable"]
+        fin = np.isfinite(want) & np.isfinite(VT)
+        assert fin.sum() > 9990
+        # (1/r^6 - 1) cancels at r = 1: compare on the scale of the two terms, not in ulps of the difference
+        assert np.all(np.abs(VT[fin] - want[fin]) <= 1e-14 * (np.abs(want[fin]) + 22.0228))
+        assert VT[0] == VT[2] and VT[c.Nmax + 1] == VT[c.Nmax]
