@@ -148,6 +148,8 @@ int pigs_sampler_init(pigs_ctx *ctx, const pigs_sweep_params *sp);
 int pigs_sampler_seed(pigs_ctx *ctx, int32_t walker, int32_t seed);
 /* continue from a generator state in the reference's block form (mti, mt(0:623)) */
 int pigs_sampler_set_rng(pigs_ctx *ctx, int32_t walker, int32_t mti, const int32_t mt[624]);
+/* the walker's generator state, again in the reference's block form (what mtsavef writes) */
+int pigs_sampler_get_rng(pigs_ctx *ctx, int32_t walker, int32_t *mti, int32_t mt[624]);
 /* one MC step (istep is the 1-based step number: CM moves when mod(istep,CMFreq)==0); asynchronous */
 int pigs_sampler_step(pigs_ctx *ctx, int32_t istep);
 /* accepted-move counters per walker since pigs_sampler_init: acc[4*w+{0,1,2,3}] = CM, head, tail, bisection */

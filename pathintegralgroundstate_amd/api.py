@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
     "pigs_set_tuning", "pigs_selftest_fastmath",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
-    "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_step",
+    "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
     "pigs_sampler_counters", "pigs_slice_download", "pigs_build_tables_kind",
 ]
 
@@ -101,6 +101,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_init.argtypes = [vp, C.POINTER(PigsSweepParams)]
     L.pigs_sampler_seed.argtypes = [vp, C.c_int32, C.c_int32]
     L.pigs_sampler_set_rng.argtypes = [vp, C.c_int32, C.c_int32, _ip]
+    L.pigs_sampler_get_rng.argtypes = [vp, C.c_int32, _ip, _ip]
     L.pigs_sampler_step.argtypes = [vp, C.c_int32]
     L.pigs_sampler_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
@@ -304,6 +305,12 @@ class PigsContext:
     def sampler_set_rng(self, walker, mti, mt):
         mt = np.ascontiguousarray(mt, np.uint32).view(np.int32)
         _chk(self.L, self.L.pigs_sampler_set_rng(self.h, int(walker), int(mti), _i(mt)), "pigs_sampler_set_rng")
+
+    def sampler_get_rng(self, walker):
+        mti = C.c_int32()
+        mt = np.zeros(624, np.int32)
+        _chk(self.L, self.L.pigs_sampler_get_rng(self.h, int(walker), C.byref(mti), _i(mt)), "pigs_sampler_get_rng")
+        return mti.value, mt.view(np.uint32).copy()
 
     def sampler_step(self, istep):
         _chk(self.L, self.L.pigs_sampler_step(self.h, int(istep)), "pigs_sampler_step")

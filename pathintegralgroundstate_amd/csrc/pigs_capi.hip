@@ -474,14 +474,22 @@ void mt_seed_words(uint32_t seed, uint32_t *w)
     w[0] = seed;
     for (int i = 1; i < 624; ++i) w[i] = 69069u * w[i - 1];
 }
-void mt_block_to_sliding(int mti, uint32_t *w, uint32_t *pos_out)
+void mt_twist_prefix(int n, uint32_t *w)
 {
-    const int n = mti > 624 ? 624 : mti;
     for (int i = 0; i < n; ++i) {
         const uint32_t y = (w[i] & 0x80000000u) | (w[(i + 1) % 624] & 0x7fffffffu);
         w[i] = w[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
-    *pos_out = (uint32_t)(n % 624);
+}
+// st: [624 sliding][624 block form][pos] from the reference's block form (mti, words)
+void mt_block_to_device(int mti, const uint32_t *words, uint32_t *st)
+{
+    uint32_t *sl = st, *blk = st + 624;
+    memcpy(blk, words, 624 * sizeof(uint32_t));
+    if (mti >= 624) { mt_twist_prefix(624, blk); mti = 0; }        // block exhausted: next block, nothing consumed
+    memcpy(sl, blk, 624 * sizeof(uint32_t));
+    mt_twist_prefix(mti, sl);                                        // consumed slots already slid on
+    st[1248] = (uint32_t)mti;
 }
 } // namespace
 
@@ -499,13 +507,14 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
     c->sweep_threads = c->n_walkers > 256 ? 256 : 1024;
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
-    if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * 625 * sizeof(uint32_t)));
+    if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * kRngWords * sizeof(uint32_t)));
     if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, (size_t)c->n_walkers * 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, (size_t)c->n_walkers * 4 * sizeof(unsigned long long), c->stream));
-    std::vector<uint32_t> st((size_t)c->n_walkers * 625);
+    std::vector<uint32_t> st((size_t)c->n_walkers * kRngWords);
     for (int w = 0; w < c->n_walkers; ++w) {
-        mt_seed_words(4357u, &st[(size_t)w * 625]);
-        mt_block_to_sliding(624, &st[(size_t)w * 625], &st[(size_t)w * 625 + 624]);
+        uint32_t seedw[624];
+        mt_seed_words(4357u, seedw);
+        mt_block_to_device(624, seedw, &st[(size_t)w * kRngWords]);
     }
     HIPCHK(hipMemcpyAsync(c->d_rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -518,11 +527,23 @@ int pigs_sampler_set_rng(pigs_ctx *c, int32_t walker, int32_t mti, const int32_t
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
     if (walker < 0 || walker >= c->n_walkers || !mt || mti < 0 || mti > 624) return fail(PIGS_ERR_ARG, "bad rng state");
-    uint32_t st[625];
-    memcpy(st, mt, 624 * sizeof(uint32_t));
-    mt_block_to_sliding(mti, st, &st[624]);
-    HIPCHK(hipMemcpyAsync(c->d_rng + (size_t)walker * 625, st, sizeof st, hipMemcpyHostToDevice, c->stream));
+    uint32_t st[kRngWords];
+    mt_block_to_device(mti, (const uint32_t *)mt, st);
+    HIPCHK(hipMemcpyAsync(c->d_rng + (size_t)walker * kRngWords, st, sizeof st, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_get_rng(pigs_ctx *c, int32_t walker, int32_t *mti, int32_t mt[624])
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
+    if (walker < 0 || walker >= c->n_walkers || !mt || !mti) return fail(PIGS_ERR_ARG, "bad rng request");
+    uint32_t st[kRngWords];
+    HIPCHK(hipMemcpyAsync(st, c->d_rng + (size_t)walker * kRngWords, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(mt, st + 624, 624 * sizeof(uint32_t));                    // block form: what mtsavef would hold
+    *mti = (int32_t)st[1248];
     return PIGS_OK;
 }
 

@@ -42,6 +42,8 @@ hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int 
                              hipStream_t st);
 
 // K6: device-resident sampler (pigs_sampler.hip)
+// per-walker generator state in global memory: 624 sliding words, 624 block-form words, position
+constexpr int kRngWords = 2 * 624 + 1;
 struct SweepParams {
     int32_t Nlev, Nstag, Lstag, do_cm;
     int32_t open_attempt, pad0, pad1, pad2;

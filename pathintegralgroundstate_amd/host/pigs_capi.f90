@@ -238,6 +238,14 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_sampler_set_rng
 
+     function pigs_sampler_get_rng(ctx,walker,mti,mt) bind(C,name='pigs_sampler_get_rng') result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value        :: ctx
+       integer(c_int32_t), value :: walker
+       integer(c_int32_t)        :: mti,mt(0:623)
+       integer(c_int) :: rc
+     end function pigs_sampler_get_rng
+
      function pigs_sampler_step(ctx,istep) bind(C,name='pigs_sampler_step') result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value        :: ctx

@@ -13,7 +13,7 @@ module pigs_rng
 
   implicit none
   private
-  public :: mt_state, mt_seed, mt_real, mt_gauss
+  public :: mt_state, mt_seed, mt_real, mt_gauss, mt_save, mt_load
 
   integer, parameter :: NW = 624, MW = 397
 
@@ -102,5 +102,30 @@ contains
     ! mu + sigma*u1*w with mu=0, sigma=1, in the reference's association order
     g = 0.d0+1.d0*u1*q
   end subroutine mt_gauss
+
+  ! generator state on disk: the two unformatted records (index, words) of the reference's
+  ! mtsavef / mtgetf (random_mod.f90:125-191).  The reference APPENDS a pair per block and reads the
+  ! first pair back (quirk Q10: a resumed run restarts from the OLDEST saved state); we replace the
+  ! file, so our own resume continues from the newest state, while a rand_state written by the
+  ! reference is read exactly as the reference reads it (first pair).
+  subroutine mt_save(s,fname)
+    type(mt_state), intent(in)   :: s
+    character(len=*), intent(in) :: fname
+    integer :: u
+    open (newunit=u,file=fname,status='replace',form='unformatted')
+    write (u) s%pos
+    write (u) s%w
+    close (u)
+  end subroutine mt_save
+
+  subroutine mt_load(s,fname)
+    type(mt_state), intent(inout) :: s
+    character(len=*), intent(in)  :: fname
+    integer :: u
+    open (newunit=u,file=fname,status='old',form='unformatted')
+    read (u) s%pos
+    read (u) s%w
+    close (u)
+  end subroutine mt_load
 
 end module pigs_rng

@@ -36,7 +36,8 @@ program pigs_vpi
   real (kind=8)     :: a_ho(3)
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios
-  logical           :: device_sampler
+  logical           :: device_sampler,checkpointing
+  integer(c_int32_t) :: rpos
   character (len=8) :: potential
   integer           :: pot_kind
   namelist /system/  dim,Np,density,crystal,trap
@@ -45,7 +46,7 @@ program pigs_vpi
   namelist /wavefun/ Nmax,wf_table,v_table
   namelist /extpot/  a_ho
   namelist /jastrow/ Rm
-  namelist /gpu/     n_walkers,device,device_sampler,potential
+  namelist /gpu/     n_walkers,device,device_sampler,potential,checkpointing
 
   type(sampler_t)    :: s
   type(est_params)   :: ep
@@ -73,7 +74,8 @@ program pigs_vpi
   real(8), allocatable :: nrho(:,:,:),AvNr(:,:,:),AvNr2(:,:,:)
   real(8) :: t0,t1,mE(3),mT(3)
   integer, allocatable :: ue(:),ut(:),uh(:)
-  integer :: ueav,utav
+  integer :: ueav,utav,ucfg
+  logical :: lflag
   integer(8) :: c0,c1,crate
   type(pigs_sweep_params) :: swp_par
   real(8), allocatable :: Rmid(:,:,:)
@@ -88,7 +90,7 @@ program pigs_vpi
   Nmax = 10000; wf_table = .false.; v_table = .false.
   CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
   delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
-  n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'
+  n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'; checkpointing = .true.
 
   read (5,nml=system,iostat=ios);  rewind (5)
   read (5,nml=samp,iostat=ios);    rewind (5)
@@ -100,10 +102,6 @@ program pigs_vpi
   read (5,nml=jastrow,iostat=ios); rewind (5)
   read (5,nml=gpu,iostat=ios);     rewind (5)
 
-  if (crystal .or. resume) then
-     write (0,*) 'pigs_vpi: crystal / resume start-up is not supported yet'
-     stop 2
-  end if
   if (.not. (wf_table .and. v_table)) then
      write (0,*) 'pigs_vpi: wf_table = T and v_table = T are required (the reference Force() is a stub)'
      stop 2
@@ -127,9 +125,18 @@ program pigs_vpi
      rcut     = 10.d0*rcut
      delta_cm = delta_cm*minval(a_ho(1:dim))
   else
-     do k=1,dim
-        Lbox(k) = (real(Np)/density)**(1.d0/real(dim))
-     end do
+     if (crystal) then
+        ! lattice start: particle number, box and density come from config_ini.in (reference vpi.f90:99-107)
+        open (newunit=ucfg,file='config_ini.in',status='old')
+        read (ucfg,*) Np
+        read (ucfg,*) (Lbox(k),k=1,dim)
+        read (ucfg,*) density
+        close (ucfg)
+     else
+        do k=1,dim
+           Lbox(k) = (real(Np)/density)**(1.d0/real(dim))
+        end do
+     end if
      rcut     = minval(0.5d0*Lbox(1:dim))
      delta_cm = delta_cm/density**(1.d0/real(dim))
   end if
@@ -160,19 +167,53 @@ program pigs_vpi
   ep%rcut2 = rcut2; ep%rbin = rbin; ep%pi = pi; ep%CWorm = CWorm
   ep%Lbox = Lbox; ep%LboxHalf = 0.5d0*Lbox; ep%qbin = 2.d0*pi/Lbox
 
-  ! initial configuration (reference vpi_mod.f90:189-254): uniform random positions, every
-  ! bead of a particle at the same point; walker w seeds its stream with seed+w-1
+  ! initial configuration (reference vpi_mod.f90:149-259): resume from checkpoint files, a lattice
+  ! from config_ini.in, or uniform random positions; every bead of a particle starts at the same
+  ! point; walker w seeds its stream with seed+w-1
   do w=1,NW
-     call mt_seed(s%rng(w),seed+w-1)
-     do ip=1,Np
-        do k=1,dim
-           if (trap) then
-              s%Path(k,ip,0,w) = 2.d0*a_ho(k)*(mt_real(s%rng(w))-0.5d0)
-           else
-              s%Path(k,ip,0,w) = Lbox(k)*(mt_real(s%rng(w))-0.5d0)
-           end if
+     suffix = ''
+     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     if (resume) then
+        open (newunit=ucfg,file='checkpoint'//trim(suffix)//'.dat',status='old')
+        read (ucfg,*) lflag                      ! trap (as written; the namelist value rules)
+        read (ucfg,*) lflag
+        s%isopen(w) = lflag
+        read (ucfg,*) s%iworm(w)
+        do ip=1,Np
+           do ib=0,2*Nb
+              read (ucfg,*) (s%Path(k,ip,ib,w),k=1,dim)
+           end do
         end do
-     end do
+        read (ucfg,*)
+        read (ucfg,*)
+        do j=1,2
+           read (ucfg,*) (s%xend(k,j,w),k=1,dim)
+        end do
+        close (ucfg)
+        call mt_load(s%rng(w),'rand_state'//trim(suffix))
+        cycle
+     end if
+     call mt_seed(s%rng(w),seed+w-1)
+     if (crystal .and. .not. trap) then
+        open (newunit=ucfg,file='config_ini.in',status='old')
+        read (ucfg,*)
+        read (ucfg,*)
+        read (ucfg,*)
+        do ip=1,Np
+           read (ucfg,*) (s%Path(k,ip,0,w),k=1,dim)
+        end do
+        close (ucfg)
+     else
+        do ip=1,Np
+           do k=1,dim
+              if (trap) then
+                 s%Path(k,ip,0,w) = 2.d0*a_ho(k)*(mt_real(s%rng(w))-0.5d0)
+              else
+                 s%Path(k,ip,0,w) = Lbox(k)*(mt_real(s%rng(w))-0.5d0)
+              end if
+           end do
+        end do
+     end if
      do ib=1,2*Nb
         s%Path(:,:,ib,w) = s%Path(:,:,0,w)
      end do
@@ -427,6 +468,44 @@ program pigs_vpi
         write (ueav,'(5g20.10e3)') real(iblock),mE/nd
         write (utav,'(5g20.10e3)') real(iblock),mT/nd
      end if
+     ! ---- checkpoint (reference vpi.f90:541-545, vpi_mod.f90:263-309): text worldline, particle-major
+     if (checkpointing) then
+        if (device_sampler) then
+           call pigs_check(pigs_path_download_all(ctx,s%Path),'pigs_path_download_all')
+           do w=1,NW
+              call pigs_check(pigs_sampler_get_rng(ctx,int(w-1,c_int32_t),rpos,s%rng(w)%w),'pigs_sampler_get_rng')
+              s%rng(w)%pos = rpos
+           end do
+        end if
+        do w=1,NW
+           suffix = ''
+           if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+           open (newunit=ucfg,file='checkpoint'//trim(suffix)//'.dat')
+           if (trap) then
+              write (ucfg,*) ".True."
+           else
+              write (ucfg,*) ".False."
+           end if
+           if (s%isopen(w)) then
+              write (ucfg,*) ".True."
+           else
+              write (ucfg,*) ".False."
+           end if
+           write (ucfg,*) s%iworm(w)
+           do ip=1,Np
+              do ib=0,2*Nb
+                 write (ucfg,*) (s%Path(k,ip,ib,w),k=1,dim)
+              end do
+           end do
+           write (ucfg,*)
+           write (ucfg,*)
+           do j=1,2
+              write (ucfg,*) (s%xend(k,j,w),k=1,dim)
+           end do
+           close (ucfg)
+           call mt_save(s%rng(w),'rand_state'//trim(suffix))
+        end do
+     end if
      call system_clock(c1)
      t0 = 0.d0; t1 = dble(c1-c0)/dble(crate)
 
@@ -463,11 +542,11 @@ program pigs_vpi
         close (k)
      end if
      if (.not. trap) then
-        if (diag_bl(w)>0) then
-           call write_radial('gr_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvGr(:,w),AvGr2(:,w))
-           call write_sk('sk_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvSk(:,:,w),AvSk2(:,:,w))
-        end if
-        if (obdm_bl(w)>0) call write_nr('nr_vpi'//trim(suffix)//'.out',ep,obdm_bl(w),AvNr(:,:,w),AvNr2(:,:,w))
+        ! written unconditionally, like the reference (a run without a single diagonal / OBDM block
+        ! yields NaN columns there too)
+        call write_radial('gr_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvGr(:,w),AvGr2(:,w))
+        call write_sk('sk_vpi'//trim(suffix)//'.out',ep,diag_bl(w),AvSk(:,:,w),AvSk2(:,:,w))
+        call write_nr('nr_vpi'//trim(suffix)//'.out',ep,obdm_bl(w),AvNr(:,:,w),AvNr2(:,:,w))
      end if
   end do
   if (NW>1) then

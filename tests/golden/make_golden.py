@@ -235,3 +235,39 @@ def make_runs():
 
 if __name__ == "__main__":
     make_runs()
+
+
+def make_resume_fixture():
+    """Reference run A (2 blocks) leaves checkpoint.dat + rand_state; reference run B resumes from them
+    for 2 more blocks (quirk Q10: it reads the FIRST rand_state record, i.e. the state after block 1)."""
+    import shutil
+    dst = os.path.join(OUT, "vpi_runs", "he4_resume")
+    os.makedirs(dst, exist_ok=True)
+    kw = dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3, Nblock=2, Nstep=15,
+              CWorm="0.5d0", Nobdm=4)
+    with tempfile.TemporaryDirectory() as td:
+        run_vpi(td, **kw)
+        shutil.copy(os.path.join(td, "checkpoint.dat"), os.path.join(dst, "checkpoint.dat"))
+        shutil.copy(os.path.join(td, "rand_state"), os.path.join(dst, "rand_state"))
+        txt = open(os.path.join(td, "vpi.in")).read().replace("resume = F", "resume = T")
+    # run B in a FRESH directory holding only the two restart files (stale output files of run A
+    # would otherwise shine through: the reference does not truncate them)
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(os.path.join(dst, "checkpoint.dat"), os.path.join(td, "checkpoint.dat"))
+        shutil.copy(os.path.join(dst, "rand_state"), os.path.join(td, "rand_state"))
+        for f in RUN_FILES:
+            if os.path.exists(os.path.join(dst, f)):
+                os.remove(os.path.join(dst, f))
+        with open(os.path.join(td, "vpi.in"), "w") as f:
+            f.write(txt)
+        with open(os.path.join(td, "vpi.in")) as fin, open(os.path.join(td, "stdout2"), "w") as fo:
+            subprocess.run([REF_VPI], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=td, check=False, timeout=600)
+        shutil.copy(os.path.join(td, "vpi.in"), os.path.join(dst, "vpi.in"))
+        for f in RUN_FILES:
+            if os.path.exists(os.path.join(td, f)):
+                shutil.copy(os.path.join(td, f), os.path.join(dst, f))
+    print("resume fixture written to", dst)
+
+
+if __name__ == "__main__":
+    make_resume_fixture()

@@ -198,6 +198,7 @@ int pigs_commit_staged(pigs_ctx *c, int64_t n) { return pigs_commit_beads(c, n, 
 int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp) { (void)c; (void)sp; snprintf(g_err, sizeof g_err, "device sampler needs a GPU"); return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_seed(pigs_ctx *c, int32_t w, int32_t s) { (void)c; (void)w; (void)s; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_set_rng(pigs_ctx *c, int32_t w, int32_t m, const int32_t mt[624]) { (void)c; (void)w; (void)m; (void)mt; return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_get_rng(pigs_ctx *c, int32_t w, int32_t *m, int32_t mt[624]) { (void)c; (void)w; (void)m; (void)mt; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_step(pigs_ctx *c, int32_t i) { (void)c; (void)i; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_counters(pigs_ctx *c, int64_t *a) { (void)c; (void)a; return PIGS_ERR_UNSUPPORTED; }
 int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)

@@ -84,3 +84,22 @@ def test_gpu_front_end_with_device_resident_sampler(exe, tmp_path):
         assert _close(tmp_path / f"et_vpi.w{w:04d}.out", os.path.join(src, "et_vpi.out"))
         assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
         assert _close(tmp_path / f"sk_vpi.w{w:04d}.out", os.path.join(src, "sk_vpi.out"), rel=1e-8)
+
+
+def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
+    """device_sampler = T: 4 blocks in one go == 2 blocks + resume for 2 more; exercises the block-form
+    generator snapshot the sampler kernel keeps for checkpoints (pigs_sampler_get_rng)."""
+    base = open(os.path.join(RUNS, "he4_bis_cworm0_s1982", "vpi.in")).read().replace("Nblock = 3", "Nblock = 4")
+    gpu = "&gpu\n n_walkers = 2, device = 0, device_sampler = T\n/\n"
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    _run(exe, base + gpu, str(a))
+    _run(exe, base.replace("Nblock = 4", "Nblock = 2") + gpu, str(b))
+    first = [open(b / f"et_vpi.w{w:04d}.out").read().splitlines() for w in range(2)]
+    _run(exe, base.replace("Nblock = 4", "Nblock = 2").replace("resume = F", "resume = T") + gpu, str(b))
+    strip = lambda ls: [l.split()[1:] for l in ls]
+    for w in range(2):
+        second = open(b / f"et_vpi.w{w:04d}.out").read().splitlines()
+        whole = open(a / f"et_vpi.w{w:04d}.out").read().splitlines()
+        assert strip(first[w]) + strip(second) == strip(whole), w
+    assert same_bits(np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin"))

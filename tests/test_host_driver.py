@@ -80,3 +80,36 @@ def test_reference_program_itself_if_present(exe, tmp_path):
     run_pigs_vpi(exe, txt, str(b))
     for f in FILES:
         assert open(a / f, "rb").read() == open(b / f, "rb").read(), f
+
+
+def test_resume_from_reference_checkpoint(exe, tmp_path):
+    """checkpoint.dat / rand_state written by the reference are read back the way the reference reads
+    them (incl. quirk Q10: the FIRST rand_state record) and the resumed run reproduces the
+    reference's resumed run byte for byte."""
+    import shutil
+    src = os.path.join(RUNS, "he4_resume")
+    shutil.copy(os.path.join(src, "checkpoint.dat"), tmp_path / "checkpoint.dat")
+    shutil.copy(os.path.join(src, "rand_state"), tmp_path / "rand_state")
+    run_pigs_vpi(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))
+    for f in FILES:
+        if os.path.exists(os.path.join(src, f)):
+            assert open(os.path.join(src, f), "rb").read() == open(tmp_path / f, "rb").read(), f
+
+
+def test_own_checkpoint_round_trip(exe, tmp_path):
+    """4 blocks in one go == 2 blocks, stop, resume for 2 more (our rand_state holds the NEWEST state)."""
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read().replace("Nblock = 6", "Nblock = 4")
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    run_pigs_vpi(exe, base, str(a))
+    run_pigs_vpi(exe, base.replace("Nblock = 4", "Nblock = 2"), str(b))
+    first = open(b / "et_vpi.out").read().splitlines()
+    run_pigs_vpi(exe, base.replace("Nblock = 4", "Nblock = 2").replace("resume = F", "resume = T"), str(b))
+    second = open(b / "et_vpi.out").read().splitlines()
+    whole = open(a / "et_vpi.out").read().splitlines()
+    strip = lambda ls: [l.split()[1:] for l in ls]          # drop the block number column
+    assert strip(first) + strip(second) == strip(whole)
+    assert same_bits(np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin"))
+    # the checkpoint is the reference's text format: trap, isopen, iworm, Np*(2Nb+1) bead lines, 2 blank, 2 xend
+    lines = open(b / "checkpoint.dat").read().split("\n")
+    assert lines[0].strip() == ".False." and len([l for l in lines if l.strip()]) == 3 + 16 * 17 + 2
