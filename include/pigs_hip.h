@@ -169,6 +169,13 @@ int pigs_therm_energy_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers,
 int pigs_local_energy_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t ib,
                             double *E, double *Kin, double *Pot);
 
+/* ---- K7: structural estimators of slice ib (vpi.f90:466-469 uses ib = Nb): PairCorrelation and
+ * StructureFactor (sample_mod.f90:392-473) for walkers[0..n).  gr(Nbin,n) receives this slice's
+ * histogram increments (+2 per pair inside the cutoff, exact), Sk(dim,Nk,n) the per-k increments.
+ * The caller accumulates and normalises as the reference does.  PBC only. */
+int pigs_structure_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t ib, int32_t Nbin,
+                         double rbin, int32_t Nk, double *gr, double *Sk);
+
 /* ---- multi-GPU: block-estimator reduction (new) ------------------------ */
 /* RCCL communicator over `nranks` contexts.  Single-process form (one host thread per
  * GPU, the Fortran host): pigs_comm_init_all.  Multi-process form: rank 0 obtains an id

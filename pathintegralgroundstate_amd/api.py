@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "pigs_set_tuning", "pigs_selftest_fastmath",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
-    "pigs_sampler_counters", "pigs_slice_download", "pigs_build_tables_kind",
+    "pigs_sampler_counters", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_step.argtypes = [vp, C.c_int32]
     L.pigs_sampler_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
+    L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     for name in ABI_SYMBOLS:
@@ -360,6 +361,18 @@ class PigsContext:
         _chk(self.L, self.L.pigs_local_energy_batch(self.h, n, None if w is None else _i(w), int(ib),
                                                     _d(E), _d(K), _d(P)), "pigs_local_energy_batch")
         return E, K, P
+
+    # ---- K7
+    def structure_batch(self, ib, Nbin, rbin, Nk, walkers=None):
+        """(gr increments (n,Nbin), Sk increments (n,Nk,dim)) of slice ib: PairCorrelation and
+        StructureFactor (reference sample_mod.f90:392-473)."""
+        w = None if walkers is None else _i32(walkers).ravel()
+        n = self.n_walkers if w is None else w.size
+        gr = np.empty((n, Nbin))
+        Sk = np.empty((n, Nk, self.cfg.dim))
+        _chk(self.L, self.L.pigs_structure_batch(self.h, n, None if w is None else _i(w), int(ib), int(Nbin),
+                                                 float(rbin), int(Nk), _d(gr), _d(Sk)), "pigs_structure_batch")
+        return gr, Sk
 
     # ---- multi-GPU
     def comm_init_rank(self, nranks, rank, unique_id: bytes):

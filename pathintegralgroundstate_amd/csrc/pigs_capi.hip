@@ -658,6 +658,31 @@ int pigs_local_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, int3
     return PIGS_OK;
 }
 
+// ---- K7 ----------------------------------------------------------------------------------
+int pigs_structure_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, int32_t ib, int32_t Nbin,
+                         double rbin, int32_t Nk, double *gr, double *Sk)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || Nbin < 1 || Nk < 0 || !(rbin > 0.0) || ib < 0 || ib >= c->P.M) return fail(PIGS_ERR_ARG, "bad structure request");
+    if (c->P.trap) return fail(PIGS_ERR_UNSUPPORTED, "structural estimators are defined for PBC runs only (vpi.f90:466)");
+    if (n == 0) return PIGS_OK;
+    if (!gr || !Sk) return fail(PIGS_ERR_ARG, "null output");
+    std::vector<int32_t> sw(n);
+    for (int i = 0; i < n; ++i) {
+        sw[i] = walkers ? walkers[i] : i;
+        if (sw[i] < 0 || sw[i] >= c->n_walkers) return fail(PIGS_ERR_ARG, "walker %d out of range", sw[i]);
+    }
+    const size_t ng = (size_t)n * Nbin, ns = (size_t)n * Nk * c->P.dim;
+    HIPCHK(c->d_slotw.reserve(n)); HIPCHK(c->d_res.reserve(ng + ns));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slotw.p, sw.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_structure(c->P, c->d_paths, n, c->d_slotw.p, ib, Nbin, rbin, Nk, c->d_res.p, c->d_res.p + ng, s));
+    HIPCHK(hipMemcpyAsync(gr, c->d_res.p, ng * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (ns) HIPCHK(hipMemcpyAsync(Sk, c->d_res.p + ng, ns * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PIGS_OK;
+}
+
 // ---- multi-GPU ---------------------------------------------------------------------------
 int pigs_comm_unique_id(char id[128])
 {

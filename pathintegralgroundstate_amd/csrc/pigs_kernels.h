@@ -35,6 +35,9 @@ hipError_t launch_local_energy(const DevParams &P, const double *paths, const do
                                const double *WF, int n_slots, const int32_t *slot_walker, int ib,
                                double *out, hipStream_t st);
 
+hipError_t launch_structure(const DevParams &P, const double *paths, int n_slots, const int32_t *slot_walker,
+                            int ib, int Nbin, double rbin, int Nk, double *gr, double *Sk, hipStream_t st);
+
 hipError_t launch_commit_beads(const DevParams &P, double *paths, int64_t n, const int32_t *walker,
                                const int32_t *ip, const int32_t *ib, const double *x, hipStream_t st);
 

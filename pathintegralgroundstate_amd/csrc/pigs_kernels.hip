@@ -209,6 +209,56 @@ __global__ __launch_bounds__(256) void k_local_energy(
 }
 
 // =====================================================================================
+// K7: structural estimators of one slice per workgroup (sample_mod.f90:392-473)
+//   gr[slot][ibin]   += 2 per pair inside the cutoff (integer counts in LDS: exact, order-free)
+//   Sk[slot][iq][k]  += (sum_i cos q x_i)^2 + (sum_i sin q x_i)^2,  q = iq*2pi/L_k, particles summed
+//                       in index order as the reference does
+// =====================================================================================
+template <int DIM>
+__global__ __launch_bounds__(256) void k_structure(
+    DevParams P, const double *__restrict__ paths, int n_slots, const int32_t *__restrict__ slot_walker,
+    int ib, int Nbin, double rbin, int Nk, double pi, double *__restrict__ gr, double *__restrict__ Sk)
+{
+    extern __shared__ double lds[];
+    double *sx = lds;                                          // DIM * NpPad
+    unsigned int *hist = reinterpret_cast<unsigned int *>(lds + DIM * P.NpPad);
+    const int slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    const int w = slot_walker ? slot_walker[slot] : slot;
+    const double *S = paths + ((size_t)w * P.M + ib) * slice_doubles(DIM, P.NpPad);
+    for (int t = threadIdx.x; t < DIM * P.NpPad; t += blockDim.x) sx[t] = S[t];
+    for (int t = threadIdx.x; t < Nbin; t += blockDim.x) hist[t] = 0u;
+    __syncthreads();
+    // pairs i<j, row i per thread (sample_mod.f90:404-425)
+    for (int i = threadIdx.x; i < P.Np - 1; i += blockDim.x) {
+        for (int j = i + 1; j < P.Np; ++j) {
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = sx[k * P.NpPad + i] - sx[k * P.NpPad + j];
+            const double r2 = min_image<DIM>(d, P);
+            if (r2 <= P.rcut2) {
+                const int ibin = (int)(sqrt(r2) / rbin);                // 0-based: int(rij/rbin)+1 - 1
+                if (ibin >= 0 && ibin < Nbin) atomicAdd(&hist[ibin], 1u);
+            }
+        }
+    }
+    // S(k): one thread per (iq, k)
+    for (int t = threadIdx.x; t < Nk * DIM; t += blockDim.x) {
+        const int iq = t / DIM + 1, k = t - (iq - 1) * DIM;
+        const double qbin = 2.0 * pi / P.Lbox[k];                      // vpi.f90:119
+        double c = 0.0, s = 0.0;
+        for (int i = 0; i < P.Np; ++i) {
+            const double qr = (double)(float)iq * qbin * sx[k * P.NpPad + i];
+            c = c + cos(qr);
+            s = s + sin(qr);
+        }
+        Sk[((size_t)slot * Nk + (iq - 1)) * DIM + k] = c * c + s * s;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Nbin; t += blockDim.x) gr[(size_t)slot * Nbin + t] = 2.0 * (double)hist[t];
+}
+
+// =====================================================================================
 // K5 and layout kernels
 // =====================================================================================
 __global__ void k_commit_beads(DevParams P, double *__restrict__ paths, int64_t n,
@@ -325,6 +375,18 @@ hipError_t launch_local_energy(const DevParams &P, const double *paths, const do
                        VT, WF, n_slots, slot_walker, ib, out)
     PIGS_DISPATCH(P, CALL);
 #undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_structure(const DevParams &P, const double *paths, int n_slots, const int32_t *slot_walker,
+                            int ib, int Nbin, double rbin, int Nk, double *gr, double *Sk, hipStream_t st)
+{
+    if (n_slots <= 0) return hipSuccess;
+    const size_t lds = (size_t)P.dim * P.NpPad * sizeof(double) + (size_t)Nbin * sizeof(unsigned int);
+    const double pi = acos(-1.0);
+    if (P.dim == 1) hipLaunchKernelGGL((k_structure<1>), dim3(n_slots), dim3(256), lds, st, P, paths, n_slots, slot_walker, ib, Nbin, rbin, Nk, pi, gr, Sk);
+    else if (P.dim == 2) hipLaunchKernelGGL((k_structure<2>), dim3(n_slots), dim3(256), lds, st, P, paths, n_slots, slot_walker, ib, Nbin, rbin, Nk, pi, gr, Sk);
+    else hipLaunchKernelGGL((k_structure<3>), dim3(n_slots), dim3(256), lds, st, P, paths, n_slots, slot_walker, ib, Nbin, rbin, Nk, pi, gr, Sk);
     return hipGetLastError();
 }
 

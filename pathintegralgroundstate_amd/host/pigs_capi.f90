@@ -268,6 +268,17 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_slice_download
 
+     ! K7: PairCorrelation + StructureFactor increments of slice ib (reference sample_mod.f90:392-473)
+     function pigs_structure_batch(ctx,n,walkers,ib,Nbin,rbin,Nk,gr,Sk) bind(C,name='pigs_structure_batch') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value             :: ctx
+       integer(c_int32_t), value      :: n,ib,Nbin,Nk
+       integer(c_int32_t), intent(in) :: walkers(*)
+       real(c_double), value          :: rbin
+       real(c_double)                 :: gr(*),Sk(*)
+       integer(c_int) :: rc
+     end function pigs_structure_batch
+
      function pigs_comm_init_all(ctxs,nranks) bind(C,name='pigs_comm_init_all') result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr)               :: ctxs(*)

@@ -78,7 +78,7 @@ program pigs_vpi
   logical :: lflag
   integer(8) :: c0,c1,crate
   type(pigs_sweep_params) :: swp_par
-  real(8), allocatable :: Rmid(:,:,:)
+  real(8), allocatable :: gr_inc(:,:),sk_inc(:,:,:)
   integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
   character(len=32) :: suffix
 
@@ -229,7 +229,7 @@ program pigs_vpi
         call pigs_check(pigs_sampler_set_rng(ctx,int(w-1,c_int32_t),int(s%rng(w)%pos,c_int32_t),s%rng(w)%w), &
              & 'pigs_sampler_set_rng')
      end do
-     allocate (Rmid(dim,Np,NW),dev_acc(4,NW),dev_acc0(4,NW))
+     allocate (gr_inc(Nbin,NW),sk_inc(dim,Nk,NW),dev_acc(4,NW),dev_acc0(4,NW))
      dev_acc0 = 0
   end if
 
@@ -393,7 +393,8 @@ program pigs_vpi
         end do
         if (nd>0) then
            if (device_sampler) then
-              if (.not. trap) call pigs_check(pigs_slice_download(ctx,int(Nb,c_int32_t),Rmid),'pigs_slice_download')
+              if (.not. trap) call pigs_check(pigs_structure_batch(ctx,int(nd,c_int32_t),wl,int(Nb,c_int32_t), &
+                   & int(Nbin,c_int32_t),rbin,int(Nk,c_int32_t),gr_inc,sk_inc),'pigs_structure_batch')
            else
               call sampler_flush(s)
            end if
@@ -415,8 +416,8 @@ program pigs_vpi
               ngr(w) = ngr(w)+1
               if (.not. trap) then
                  if (device_sampler) then
-                    call pair_correlation(ep,Rmid(:,:,w),gr(:,w))
-                    call structure_factor(ep,Rmid(:,:,w),Sk(:,:,w))
+                    gr(:,w)   = gr(:,w)+gr_inc(:,i)
+                    Sk(:,:,w) = Sk(:,:,w)+sk_inc(:,:,i)
                  else
                     call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
                     call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))

@@ -208,6 +208,20 @@ int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)
     return PIGS_OK;
 }
 
+int pigs_structure_batch(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t ib, int32_t Nbin, double rbin, int32_t Nk,
+                         double *gr, double *Sk)
+{
+    const size_t d = c->s.dim;
+    memset(gr, 0, (size_t)n * Nbin * sizeof(double));
+    memset(Sk, 0, (size_t)n * Nk * d * sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        const double *R = c->paths + c->wl * (ws ? ws[i] : i) + (size_t)ib * d * c->s.Np;
+        po_pair_correlation(&c->s, Nbin, rbin, R, gr + (size_t)i * Nbin);
+        po_structure_factor(&c->s, Nk, R, Sk + (size_t)i * Nk * d);
+    }
+    return PIGS_OK;
+}
+
 int pigs_comm_unique_id(char id[128]) { memset(id, 0, 128); return PIGS_OK; }
 int pigs_comm_init_rank(pigs_ctx *c, int32_t n, int32_t r, const char id[128]) { (void)c; (void)n; (void)r; (void)id; return PIGS_OK; }
 int pigs_comm_init_all(pigs_ctx **c, int32_t n) { (void)c; (void)n; return PIGS_OK; }

@@ -397,3 +397,24 @@ def test_host_pointer_batch_rate_is_reported(gpu_lib):
 def SystemConfigC3():
     from pathintegralgroundstate_amd import SystemConfig
     return SystemConfig(dim=3, Np=256, Nb=80)
+
+
+def test_structure_estimators_vs_oracle(gpu_lib, oracle):
+    """K7: g(r) histogram increments are exact (integer counts); S(k) agrees to 1e-12 (device sin/cos)."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    for Np, Nb in ((64, 6), (37, 4)):
+        S = System(dim=3, Np=Np, Nb=Nb)
+        cfg = SystemConfig(dim=3, Np=Np, Nb=Nb)
+        VT, WF = oracle.tables(S)
+        Paths = _worldlines(oracle, S, 3, 21, 0.2)
+        with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=3) as ctx:
+            ctx.upload_all(Paths)
+            gr, Sk = ctx.structure_batch(Nb, S.Nbin, S.rbin, 50)
+            gr1, Sk1 = ctx.structure_batch(1, S.Nbin, S.rbin, 50, walkers=[2])
+        for w in range(3):
+            assert same_bits(gr[w], oracle.pair_correlation(S, Paths[w][Nb]))
+            want = oracle.structure_factor(S, 50, Paths[w][Nb])
+            assert np.all(np.abs(Sk[w] - want) <= 1e-12 * (np.abs(want) + Np))
+        assert same_bits(gr1[0], oracle.pair_correlation(S, Paths[2][1]))
+        assert gr.sum() > 0
