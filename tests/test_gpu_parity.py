@@ -418,3 +418,56 @@ def test_structure_estimators_vs_oracle(gpu_lib, oracle):
             assert np.all(np.abs(Sk[w] - want) <= 1e-12 * (np.abs(want) + Np))
         assert same_bits(gr1[0], oracle.pair_correlation(S, Paths[2][1]))
         assert gr.sum() > 0
+
+
+@pytest.mark.parametrize("kw", [dict(dim=1, Np=2, Nb=3, density=0.2), dict(dim=1, Np=5, Nb=2, density=0.3),
+                                dict(dim=2, Np=3, Nb=1, density=0.1), dict(dim=3, Np=300, Nb=2),
+                                dict(dim=3, Np=65, Nb=3, Nmax=64), dict(dim=2, Np=130, Nb=2, trap=True, a_ho=[2.0, 2.5])])
+def test_edge_shapes_all_kernels(gpu_lib, oracle, kw):
+    """Ragged / minimal / oversized shapes: Np=2, Np not a multiple of the wave or of the padding,
+    Np > 256 (more passes than any variant's fast path), a coarse table, 1D and 2D boxes, a wide trap."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(**kw)
+    cfg = SystemConfig(**{k: v for k, v in kw.items()})
+    VT, WF = oracle.tables(S)
+    rng = np.random.default_rng(S.Np * 7 + S.dim)
+    W = 2
+    if S.trap:
+        Paths = rng.normal(0, 1.5, (W, S.M, S.Np, S.dim))
+    else:
+        L = np.asarray(S.Lbox[:S.dim])
+        Paths = rng.uniform(-0.5, 0.5, (W, S.M, S.Np, S.dim)) * L
+    n = 400
+    w = rng.integers(0, W, n).astype(np.int32)
+    ip = rng.integers(1, S.Np + 1, n).astype(np.int32)
+    ib = rng.integers(0, S.M, n).astype(np.int32)
+    xold = Paths[w, ib, ip - 1].copy()
+    xnew = xold + rng.normal(0, 0.3, xold.shape)
+    if not S.trap:
+        xnew = np.where(xnew > L / 2, xnew - L, xnew)
+        xnew = np.where(xnew < -L / 2, xnew + L, xnew)
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w, ip, ib, xnew, xold)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        assert same_bits(ctx.download_all(), Paths)
+        for variant in (1, 2, 3, 4, 5):
+            ctx.set_tuning("k1_variant", variant)
+            got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), variant
+            fin = np.isfinite(want)
+            assert np.all(np.abs(got - want)[fin] <= 1e-9 * np.abs(want[fin]) + 1e-9 * np.max(np.abs(want[fin]), initial=0)), variant
+        E, Ec, Ep = ctx.therm_energy_batch()
+        le = ctx.local_energy_batch(2 * S.Nb)
+        pot = [ctx.PotentialEnergy(1, ib_, True) for ib_ in range(S.M)]
+    for k in range(W):
+        te = np.array(oracle.therm_energy(S, VT, Paths[k]))
+        if np.all(np.isfinite(te)):
+            assert _close_rel([E[k], Ec[k], Ep[k]], te, 1e-9)
+        lo = np.array(oracle.local_energy(S, WF, VT, Paths[k][2 * S.Nb]))
+        if np.all(np.isfinite(lo)):
+            assert _close_rel([le[0][k], le[1][k], le[2][k]], lo, 1e-9)
+    for ib_ in range(S.M):
+        p = np.array(oracle.potential_energy(S, VT, Paths[1][ib_], True))
+        if np.all(np.isfinite(p)):
+            assert _close_rel(pot[ib_], p, 1e-9)
