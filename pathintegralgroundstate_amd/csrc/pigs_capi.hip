@@ -228,8 +228,12 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
 {
     if (!c || !key) return fail(PIGS_ERR_ARG, "null pointer");
     if (!strcmp(key, "k1_variant")) {
-        if (value < K1_AUTO || value > K1_V2_LDS_COMPACT) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
+        if (value < K1_AUTO || value > K1_V2_PREFETCH) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
         c->k1_variant = value;
+        return PIGS_OK;
+    }
+    if (!strcmp(key, "sweep_debug")) {          // bit 0: skip the Delta-S evaluation of bisection stages (timing only)
+        c->sweep.pad0 = value;
         return PIGS_OK;
     }
     if (!strcmp(key, "sweep_threads")) {

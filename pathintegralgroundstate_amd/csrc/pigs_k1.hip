@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 // =====================================================================================
 // LDS layout (dynamic): [VTable copy: Nmax+2 doubles, if LDSTAB][per wave: kWaveLds bytes = reduction
 // scratch (8 x 65 doubles), whose head doubles as the 512 x u16 code list of COMPACT]
-template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK>
+template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK, bool PREFETCH = false>
 __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
     DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
     const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
@@ -217,6 +217,8 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
             if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
             else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
             else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
+        } else if (PREFETCH) {
+            item_eval_prefetch<DIM, TRAP>(P, VT, WF, S, p, b, xn, xo, lane, red, o, q);
         } else {
             item_eval<DIM, TRAP>(P, VT, WF, S, p, b, xn, xo, lane, red, o, q);
         }
@@ -287,6 +289,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     if (variant == K1_AUTO) variant = K1_V2;
     if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
     if ((variant == K1_V2_LDS || variant == K1_V2_LDS_COMPACT) && !can_ldstab) variant = K1_V2;
+    if (variant == K1_V2_PREFETCH && P.Np > 256) variant = K1_V2;
     hipError_t e = hipSuccess;
     switch (variant) {
     case K1_V1: {
@@ -301,6 +304,15 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
         const size_t lds = 4 * kWaveLds;
 #define CALL(D, T)                                                                                      \
     hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256>), dim3(k1_grid(n_items, 4, 1 << 22)),   \
+                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_V2_PREFETCH: {
+        const size_t lds = 4 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
                        dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
         PIGS_DISPATCH(P, CALL);
 #undef CALL

@@ -120,31 +120,69 @@ __device__ __forceinline__ void trap_terms(const DevParams &P, const double (&xn
     }
 }
 
-// partner j of the moved particle p: both distances, cutoff tests, accumulate
+// partner at rj[] of the moved particle: both distances, cutoff tests, accumulate
+template <int DIM, bool TRAP, int CLS, typename VTab>
+__device__ __forceinline__ void partner_accumulate_at(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                                      const double (&rj)[DIM], const double (&xn)[DIM],
+                                                      const double (&xo)[DIM], Acc<DIM, CLS> &A)
+{
+    double dnew[DIM], dold[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        dnew[k] = xn[k] - rj[k];                                      // :2706-2707
+        dold[k] = xo[k] - rj[k];
+    }
+    double r2n, r2o;
+    if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+    else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
+    if (TRAP || r2n <= P.rcut2)                                       // :2723 (Q5) / :2771
+        pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
+    const bool in_o = r2o <= P.rcut2;                                 // :2745 / :2795
+    if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
+    else if (TRAP && CLS == CLS_END)                                  // UpdateWf's trap branch has no cutoff
+        pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
+}
+
+// partner j of the moved particle p (row p itself is never read: vpi_mod.f90:2699)
 template <int DIM, bool TRAP, int CLS, typename VTab>
 __device__ __forceinline__ void partner_accumulate(const DevParams &P, VTab VT, const double *__restrict__ WF,
                                                    const double *__restrict__ S, int p, int j,
                                                    const double (&xn)[DIM], const double (&xo)[DIM],
                                                    Acc<DIM, CLS> &A)
 {
-    if (j < P.Np && j != p) {                                         // :2699: row ip is never read
-        double dnew[DIM], dold[DIM];
+    if (j < P.Np && j != p) {
+        double rj[DIM];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double rj = S[(size_t)k * P.NpPad + j];
-            dnew[k] = xn[k] - rj;                                     // :2706-2707
-            dold[k] = xo[k] - rj;
-        }
-        double r2n, r2o;
-        if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
-        else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
-        if (TRAP || r2n <= P.rcut2)                                   // :2723 (Q5) / :2771
-            pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);
-        const bool in_o = r2o <= P.rcut2;                             // :2745 / :2795
-        if (in_o) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A);
-        else if (TRAP && CLS == CLS_END)                              // UpdateWf's trap branch has no cutoff
-            pair_accumulate<DIM, CLS, true>(P, VT, WF, r2o, dold, A, false);
+        for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + j];
+        partner_accumulate_at<DIM, TRAP, CLS>(P, VT, WF, rj, xn, xo, A);
     }
+}
+
+// same item with the partner coordinates of up to 4 passes (Np <= 256) requested up front, so that
+// one memory latency is exposed per item instead of one per pass
+template <int DIM, bool TRAP, int CLS, typename VTab>
+__device__ __forceinline__ void item_direct_prefetch(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                                     const double *__restrict__ S, int p, const double (&xn)[DIM],
+                                                     const double (&xo)[DIM], int lane, int b, double *red,
+                                                     double *out, double *parts)
+{
+    constexpr int MAXP = 4;
+    Acc<DIM, CLS> A;
+    if (TRAP && lane == 0) trap_terms<DIM, TRAP, CLS>(P, xn, xo, A);
+    double rj[MAXP][DIM];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        const int j = m * kWave + lane;
+        const int jj = j < P.Np ? j : 0;                              // in-bounds dummy for idle lanes
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) rj[m][k] = S[(size_t)k * P.NpPad + jj];
+    }
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        const int j = m * kWave + lane;
+        if (j < P.Np && j != p) partner_accumulate_at<DIM, TRAP, CLS>(P, VT, WF, rj[m], xn, xo, A);
+    }
+    finish_item<DIM, CLS>(P, lane, b, A, red, out, parts);
 }
 
 // one item, every partner visited by its lane (no compaction)
@@ -283,6 +321,18 @@ __device__ __forceinline__ void item_compact(const DevParams &P, VTab VT, const 
     finish_item<DIM, CLS>(P, lane, b, A, red, out, parts);
 }
 
+
+template <int DIM, bool TRAP, typename VTab>
+__device__ __forceinline__ void item_eval_prefetch(const DevParams &P, VTab VT, const double *__restrict__ WF,
+                                                   const double *__restrict__ S, int p, int b, const double (&xn)[DIM],
+                                                   const double (&xo)[DIM], int lane, double *red, double *out, double *parts)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       item_direct_prefetch<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+    else if (endb) item_direct_prefetch<DIM, TRAP, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+    else           item_direct_prefetch<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+}
 
 // UpdateAction's three cases, chosen per item (wave-uniform)
 template <int DIM, bool TRAP, typename VTab>

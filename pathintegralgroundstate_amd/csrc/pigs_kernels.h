@@ -16,7 +16,8 @@ enum K1Variant {
     K1_V2 = 2,              // exact short division, fused sqrt/rinv, shared butterfly
     K1_V2_LDS = 3,          // + VTable in LDS
     K1_V2_COMPACT = 4,      // + in-cutoff compaction (global table)
-    K1_V2_LDS_COMPACT = 5   // + both
+    K1_V2_LDS_COMPACT = 5,  // + both
+    K1_V2_PREFETCH = 6      // v2 with all partner loads of an item issued up front (Np <= 256)
 };
 
 hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,

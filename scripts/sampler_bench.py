@@ -24,6 +24,8 @@ def main():
         ctx = api.PigsContext(cfg, VT, WF, n_walkers=W)
         ctx.upload_all(Paths)
         ctx.sampler_init()
+        if os.environ.get('SWEEP_DEBUG'):
+            ctx.set_tuning('sweep_debug', int(os.environ['SWEEP_DEBUG']))
         if os.environ.get('SWEEP_THREADS'):
             ctx.set_tuning('sweep_threads', int(os.environ['SWEEP_THREADS']))
         for w in range(W):
