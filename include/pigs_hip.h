@@ -136,12 +136,16 @@ int pigs_swap_tails(pigs_ctx *ctx, int32_t walker, int32_t iw, int32_t ik);
  * with the movers TranslateChain, MoveHeadBisection, MoveTailBisection, Bisection of vpi_mod.f90).
  * One launch advances EVERY resident walker by one MC step with no host round trip: random
  * numbers (each walker's own MT19937 stream, identical to the reference's for its seed),
- * proposals, Delta S, Metropolis and commit all run on the GPU.  The worm sector is not sampled
- * here: with CWorm = 0 the reference's never-accepted open attempt (quirk Q11) is drawn so that the
- * stream stays aligned; CWorm > 0 runs use the host-driven sampler. */
+ * proposals, Delta S, Metropolis and commit all run on the GPU.  With CWorm > 0 the worm sector is
+ * sampled too (OpenChain, CloseChain, TranslateHalfChain, MoveHead/TailHalfChain, StagingHalfChain,
+ * Swap, OBDM histogram: vpi_mod.f90:383-476,1376-2487, sample_mod.f90:477-526); with CWorm = 0 the
+ * reference's never-accepted open attempt (quirk Q11) is drawn so that the stream stays aligned. */
 typedef struct pigs_sweep_params {
     int32_t Nlev, Nstag, CMFreq, Lstag;   /* namelist samp: bisection level, repetitions, CM period, Lstag */
     double  delta_cm;                     /* effective CM step (vpi.f90:93/123 scaling already applied)      */
+    /* worm sector (namelist obdm); CWorm = 0 keeps every walker in the diagonal sector */
+    double  CWorm, density, rbin;         /* rbin = rcut/real(Nbin) (vpi.f90:128), for the OBDM histogram     */
+    int32_t swapping, Nobdm, Nbin, Npw;
 } pigs_sweep_params;
 int pigs_sampler_init(pigs_ctx *ctx, const pigs_sweep_params *sp);
 /* seed walker's stream as the reference's sgrnd(seed) does */
@@ -154,6 +158,18 @@ int pigs_sampler_get_rng(pigs_ctx *ctx, int32_t walker, int32_t *mti, int32_t mt
 int pigs_sampler_step(pigs_ctx *ctx, int32_t istep);
 /* accepted-move counters per walker since pigs_sampler_init: acc[4*w+{0,1,2,3}] = CM, head, tail, bisection */
 int pigs_sampler_counters(pigs_ctx *ctx, int64_t *acc);
+/* accepted/attempted counters per walker since pigs_sampler_init, 16 per walker:
+ * 0 cm 1 head 2 tail 3 bisection 4 try_open 5 acc_open 6 try_close 7 acc_close 8 cm_half 9 head_half
+ * 10 tail_half 11 staging_half 12 try_swap 13 acc_swap 14 try_cm 15 try_stag */
+int pigs_sampler_counters16(pigs_ctx *ctx, int64_t *cnt);
+/* worm state of every walker: isopen[w], iworm[w] (1-based), xend(dim,2,w) */
+int pigs_sampler_get_worm(pigs_ctx *ctx, int32_t *isopen, int32_t *iworm, double *xend);
+int pigs_sampler_set_worm(pigs_ctx *ctx, const int32_t *isopen, const int32_t *iworm, const double *xend);
+/* events of the LAST step, 64 ints per walker: [0] n, [1] isopen after the step, then (code,arg) pairs in
+ * order: 1 open accepted (arg iworm) 2 close accepted 3 swap accepted (arg partner) */
+int pigs_sampler_events(pigs_ctx *ctx, int32_t *events);
+/* OBDM histogram nrho(0:Npw,Nbin,w) accumulated on the device since the last reset */
+int pigs_sampler_nrho(pigs_ctx *ctx, double *nrho, int32_t reset);
 /* slice ib of every walker in the reference layout R(dim,Np,n_walkers) (for host-side g(r), S(k)) */
 int pigs_slice_download(pigs_ctx *ctx, int32_t ib, double *R);
 

@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "pigs_set_tuning", "pigs_selftest_fastmath",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
-    "pigs_sampler_counters", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
+    "pigs_sampler_counters", "pigs_sampler_counters16", "pigs_sampler_get_worm", "pigs_sampler_set_worm",
+    "pigs_sampler_events", "pigs_sampler_nrho", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
 ]
 
 
@@ -45,7 +46,8 @@ class PigsError(RuntimeError):
 
 class PigsSweepParams(C.Structure):
     _fields_ = [("Nlev", C.c_int32), ("Nstag", C.c_int32), ("CMFreq", C.c_int32), ("Lstag", C.c_int32),
-                ("delta_cm", C.c_double)]
+                ("delta_cm", C.c_double), ("CWorm", C.c_double), ("density", C.c_double), ("rbin", C.c_double),
+                ("swapping", C.c_int32), ("Nobdm", C.c_int32), ("Nbin", C.c_int32), ("Npw", C.c_int32)]
 
 
 class PigsParams(C.Structure):
@@ -104,6 +106,11 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_get_rng.argtypes = [vp, C.c_int32, _ip, _ip]
     L.pigs_sampler_step.argtypes = [vp, C.c_int32]
     L.pigs_sampler_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pigs_sampler_counters16.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.pigs_sampler_get_worm.argtypes = [vp, _ip, _ip, _dp]
+    L.pigs_sampler_set_worm.argtypes = [vp, _ip, _ip, _dp]
+    L.pigs_sampler_events.argtypes = [vp, _ip]
+    L.pigs_sampler_nrho.argtypes = [vp, _dp, C.c_int32]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
@@ -293,11 +300,15 @@ class PigsContext:
                                                         d_xold, d_out), "pigs_delta_action_batch_dev")
 
     # ---- K6: device-resident sampler
-    def sampler_init(self, Nlev=None, Nstag=None, CMFreq=None, Lstag=None, delta_cm=None):
+    def sampler_init(self, Nlev=None, Nstag=None, CMFreq=None, Lstag=None, delta_cm=None, CWorm=0.0,
+                     swapping=False, Nobdm=0, Nbin=None, Npw=0):
         c = self.cfg
+        self._nbin = c.Nbin if Nbin is None else Nbin
+        self._npw = Npw
         sp = PigsSweepParams(c.Nlev if Nlev is None else Nlev, c.Nstag if Nstag is None else Nstag,
                              c.CMFreq if CMFreq is None else CMFreq, c.Lstag if Lstag is None else Lstag,
-                             c.delta_cm_eff if delta_cm is None else delta_cm)
+                             c.delta_cm_eff if delta_cm is None else delta_cm, CWorm, c.density,
+                             c.rcut / float(np.float32(self._nbin)), int(swapping), Nobdm, self._nbin, Npw)
         _chk(self.L, self.L.pigs_sampler_init(self.h, C.byref(sp)), "pigs_sampler_init")
 
     def sampler_seed(self, walker, seed):
@@ -321,6 +332,32 @@ class PigsContext:
         _chk(self.L, self.L.pigs_sampler_counters(self.h, acc.ctypes.data_as(C.POINTER(C.c_int64))),
              "pigs_sampler_counters")
         return acc
+
+    def sampler_counters16(self):
+        acc = np.zeros((self.n_walkers, 16), np.int64)
+        _chk(self.L, self.L.pigs_sampler_counters16(self.h, acc.ctypes.data_as(C.POINTER(C.c_int64))),
+             "pigs_sampler_counters16")
+        return acc
+
+    def sampler_get_worm(self):
+        W, d = self.n_walkers, self.cfg.dim
+        isopen, iworm, xend = np.zeros(W, np.int32), np.zeros(W, np.int32), np.zeros((W, 2, d))
+        _chk(self.L, self.L.pigs_sampler_get_worm(self.h, _i(isopen), _i(iworm), _d(xend)), "pigs_sampler_get_worm")
+        return isopen.astype(bool), iworm, xend
+
+    def sampler_set_worm(self, isopen, iworm, xend):
+        isopen, iworm, xend = _i32(isopen), _i32(iworm), _f64(xend)
+        _chk(self.L, self.L.pigs_sampler_set_worm(self.h, _i(isopen), _i(iworm), _d(xend)), "pigs_sampler_set_worm")
+
+    def sampler_events(self):
+        ev = np.zeros((self.n_walkers, 64), np.int32)
+        _chk(self.L, self.L.pigs_sampler_events(self.h, _i(ev)), "pigs_sampler_events")
+        return ev
+
+    def sampler_nrho(self, reset=False):
+        out = np.zeros((self.n_walkers, self._nbin, self._npw + 1))
+        _chk(self.L, self.L.pigs_sampler_nrho(self.h, _d(out), int(reset)), "pigs_sampler_nrho")
+        return out
 
     def slice_download(self, ib):
         R = np.empty((self.n_walkers, self.cfg.Np, self.cfg.dim))

@@ -98,6 +98,9 @@ struct pigs_ctx {
     // device-resident sampler
     uint32_t   *d_rng = nullptr;
     unsigned long long *d_counters = nullptr;
+    double     *d_worm = nullptr, *d_nrho = nullptr, *d_dklog = nullptr;
+    int        *d_evlog = nullptr;
+    size_t      nrho_doubles = 0;
     SweepParams sweep{};
     int         cm_freq = 1;
     int         sweep_threads = 512;
@@ -201,6 +204,10 @@ int pigs_ctx_destroy(pigs_ctx *c)
     c->st_w.release(); c->st_ip.release(); c->st_ib.release(); c->st_xn.release(); c->st_xo.release(); c->st_out.release();
     c->cs_w.release(); c->cs_ip.release(); c->cs_ib.release(); c->cs_x.release();
     if (c->d_rng) (void)hipFree(c->d_rng);
+    if (c->d_worm) (void)hipFree(c->d_worm);
+    if (c->d_nrho) (void)hipFree(c->d_nrho);
+    if (c->d_dklog) (void)hipFree(c->d_dklog);
+    if (c->d_evlog) (void)hipFree(c->d_evlog);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_VT) (void)hipFree(c->d_VT);
@@ -504,24 +511,52 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     if (sp->Nlev < 1 || (1 << sp->Nlev) > 16 || (1 << sp->Nlev) > 2 * c->P.Nb || sp->Nstag < 0 || sp->CMFreq < 1 ||
         sp->Lstag < 2 || sp->Lstag > c->P.Nb)
         return fail(PIGS_ERR_ARG, "sweep params out of range (Nlev=%d Nstag=%d CMFreq=%d Lstag=%d)", sp->Nlev, sp->Nstag, sp->CMFreq, sp->Lstag);
-    c->sweep.Nlev = sp->Nlev; c->sweep.Nstag = sp->Nstag; c->sweep.Lstag = sp->Lstag;
-    c->sweep.delta_cm = sp->delta_cm; c->sweep.open_attempt = 1; c->sweep.do_cm = 1;
+    const bool worm = sp->CWorm > 0.0;
+    if (worm && (sp->Nobdm < 0 || sp->Nbin < 1 || sp->Npw < 0 || !(sp->rbin > 0.0) || !(sp->density > 0.0)))
+        return fail(PIGS_ERR_ARG, "worm parameters out of range");
+    if (worm && 2 + 2 * (1 + sp->Nobdm) > kEvInts) return fail(PIGS_ERR_UNSUPPORTED, "Nobdm=%d exceeds the event log", sp->Nobdm);
+    SweepParams &k = c->sweep;
+    memset(&k, 0, sizeof k);
+    k.Nlev = sp->Nlev; k.Nstag = sp->Nstag; k.Lstag = sp->Lstag;
+    k.delta_cm = sp->delta_cm; k.open_attempt = 1; k.do_cm = 1;
+    k.worm = worm; k.swapping = sp->swapping != 0; k.Nobdm = worm ? sp->Nobdm : 0;
+    k.Nbin = worm ? sp->Nbin : 1; k.Npw = worm ? sp->Npw : 0; k.rbin = worm ? sp->rbin : 1.0;
+    k.log_cworm_density = worm ? std::log(sp->CWorm * sp->density) : 0.0;      // host libm, as the reference
     c->cm_freq = sp->CMFreq;
     // one workgroup per walker: 16 waves when every walker gets a CU of its own, 4 waves (3 workgroups
     // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
     c->sweep_threads = c->n_walkers > 256 ? 256 : 1024;
+    if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) c->sweep_threads = 512;
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
-    if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, (size_t)c->n_walkers * kRngWords * sizeof(uint32_t)));
-    if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, (size_t)c->n_walkers * 4 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, (size_t)c->n_walkers * 4 * sizeof(unsigned long long), c->stream));
-    std::vector<uint32_t> st((size_t)c->n_walkers * kRngWords);
-    for (int w = 0; w < c->n_walkers; ++w) {
+    const size_t W = c->n_walkers;
+    if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, W * kRngWords * sizeof(uint32_t)));
+    if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, W * kCounters * sizeof(unsigned long long)));
+    if (!c->d_worm) HIPCHK(hipMalloc((void **)&c->d_worm, W * kWormDoubles * sizeof(double)));
+    if (!c->d_evlog) HIPCHK(hipMalloc((void **)&c->d_evlog, W * kEvInts * sizeof(int)));
+    if (c->d_nrho) { HIPCHK(hipFree(c->d_nrho)); c->d_nrho = nullptr; }
+    c->nrho_doubles = W * (size_t)k.Nbin * (k.Npw + 1);
+    HIPCHK(hipMalloc((void **)&c->d_nrho, c->nrho_doubles * sizeof(double)));
+    if (c->d_dklog) { HIPCHK(hipFree(c->d_dklog)); c->d_dklog = nullptr; }
+    // 0.5d0*real(dim)*log(2.d0*pi*real(Ls)*dt) of vpi_mod.f90:1873, tabulated with the host libm
+    std::vector<double> dk(sp->Lstag + 2, 0.0);
+    const double pi = std::acos(-1.0);
+    for (int Ls = 1; Ls <= sp->Lstag + 1; ++Ls)
+        dk[Ls] = 0.5 * (double)(float)c->P.dim * std::log(2.0 * pi * (double)(float)Ls * c->P.dt);
+    HIPCHK(hipMalloc((void **)&c->d_dklog, dk.size() * sizeof(double)));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_dklog, dk.data(), dk.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, W * kCounters * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(c->d_worm, 0, W * kWormDoubles * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(c->d_evlog, 0, W * kEvInts * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(c->d_nrho, 0, c->nrho_doubles * sizeof(double), s));
+    std::vector<uint32_t> st(W * kRngWords);
+    for (size_t w = 0; w < W; ++w) {
         uint32_t seedw[624];
         mt_seed_words(4357u, seedw);
-        mt_block_to_device(624, seedw, &st[(size_t)w * kRngWords]);
+        mt_block_to_device(624, seedw, &st[w * kRngWords]);
     }
-    HIPCHK(hipMemcpyAsync(c->d_rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
     c->sampler_ready = true;
     return PIGS_OK;
 }
@@ -564,15 +599,78 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
     SweepParams sp = c->sweep;
     sp.do_cm = (istep % c->cm_freq) == 0;
-    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters, c->stream));
+    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters,
+                        c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_counters16(pigs_ctx *c, int64_t *cnt)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !cnt) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    HIPCHK(hipMemcpyAsync(cnt, c->d_counters, (size_t)c->n_walkers * kCounters * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return PIGS_OK;
 }
 
 int pigs_sampler_counters(pigs_ctx *c, int64_t *acc)
 {
+    if (!c || !acc) return fail(PIGS_ERR_ARG, "null pointer");
+    std::vector<int64_t> all((size_t)c->n_walkers * kCounters);
+    int rc = pigs_sampler_counters16(c, all.data()); if (rc) return rc;
+    for (int w = 0; w < c->n_walkers; ++w)
+        for (int q = 0; q < 4; ++q) acc[4 * w + q] = all[(size_t)w * kCounters + q];
+    return PIGS_OK;
+}
+
+int pigs_sampler_get_worm(pigs_ctx *c, int32_t *isopen, int32_t *iworm, double *xend)
+{
     int rc = check_ctx(c); if (rc) return rc;
-    if (!c->sampler_ready || !acc) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
-    HIPCHK(hipMemcpyAsync(acc, c->d_counters, (size_t)c->n_walkers * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (!c->sampler_ready || !isopen || !iworm || !xend) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    std::vector<double> h((size_t)c->n_walkers * kWormDoubles);
+    HIPCHK(hipMemcpyAsync(h.data(), c->d_worm, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int d = c->P.dim;
+    for (int w = 0; w < c->n_walkers; ++w) {
+        isopen[w] = (int32_t)h[(size_t)w * kWormDoubles];
+        iworm[w]  = (int32_t)h[(size_t)w * kWormDoubles + 1];
+        for (int t = 0; t < 2 * d; ++t) xend[(size_t)w * 2 * d + t] = h[(size_t)w * kWormDoubles + 2 + t];
+    }
+    return PIGS_OK;
+}
+
+int pigs_sampler_set_worm(pigs_ctx *c, const int32_t *isopen, const int32_t *iworm, const double *xend)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !isopen || !iworm || !xend) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null input");
+    std::vector<double> h((size_t)c->n_walkers * kWormDoubles, 0.0);
+    const int d = c->P.dim;
+    for (int w = 0; w < c->n_walkers; ++w) {
+        if (isopen[w] && (iworm[w] < 1 || iworm[w] > c->P.Np)) return fail(PIGS_ERR_ARG, "walker %d: iworm=%d", w, iworm[w]);
+        h[(size_t)w * kWormDoubles]     = isopen[w] ? 1.0 : 0.0;
+        h[(size_t)w * kWormDoubles + 1] = (double)iworm[w];
+        for (int t = 0; t < 2 * d; ++t) h[(size_t)w * kWormDoubles + 2 + t] = xend[(size_t)w * 2 * d + t];
+    }
+    HIPCHK(hipMemcpyAsync(c->d_worm, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_events(pigs_ctx *c, int32_t *events)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !events) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    HIPCHK(hipMemcpyAsync(events, c->d_evlog, (size_t)c->n_walkers * kEvInts * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PIGS_OK;
+}
+
+int pigs_sampler_nrho(pigs_ctx *c, double *nrho, int32_t reset)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !nrho) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    HIPCHK(hipMemcpyAsync(nrho, c->d_nrho, c->nrho_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIPCHK(hipMemsetAsync(c->d_nrho, 0, c->nrho_doubles * sizeof(double), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PIGS_OK;
 }

@@ -48,13 +48,18 @@ hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int 
 // K6: device-resident sampler (pigs_sampler.hip)
 // per-walker generator state in global memory: 624 sliding words, 624 block-form words, position
 constexpr int kRngWords = 2 * 624 + 1;
+constexpr int kCounters = 16;       // per-walker move counters (pigs_sampler.hip)
+constexpr int kWormDoubles = 8;     // isopen, iworm, xend(:,1), xend(:,2)
+constexpr int kEvInts = 64;         // event log of one MC step
 struct SweepParams {
     int32_t Nlev, Nstag, Lstag, do_cm;
-    int32_t open_attempt, pad0, pad1, pad2;
-    double  delta_cm;
+    int32_t open_attempt, pad0, worm, swapping;   // worm: CWorm > 0 (open/close/swap sector sampled)
+    int32_t Nobdm, Nbin, Npw, pad3;
+    double  delta_cm, log_cworm_density, rbin;
 };
 hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,
-                        const double *WF, uint32_t *rng, unsigned long long *counters, hipStream_t st);
+                        const double *WF, uint32_t *rng, unsigned long long *counters, double *worm,
+                        int *evlog, double *nrho, const double *dklog, hipStream_t st);
 hipError_t launch_slice_gather(const DevParams &P, const double *paths, int ib, double *out, hipStream_t st);
 size_t sweep_lds_bytes(const DevParams &P, const SweepParams &sp, int threads);
 

@@ -21,6 +21,8 @@ module pigs_capi
   type, bind(C) :: pigs_sweep_params
      integer(c_int32_t) :: Nlev, Nstag, CMFreq, Lstag
      real(c_double)     :: delta_cm
+     real(c_double)     :: CWorm, density, rbin
+     integer(c_int32_t) :: swapping, Nobdm, Nbin, Npw
   end type pigs_sweep_params
 
   type, bind(C) :: pigs_params
@@ -259,6 +261,44 @@ module pigs_capi
        integer(c_int64_t) :: acc(*)
        integer(c_int) :: rc
      end function pigs_sampler_counters
+
+     function pigs_sampler_counters16(ctx,cnt) bind(C,name='pigs_sampler_counters16') result(rc)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t) :: cnt(*)
+       integer(c_int) :: rc
+     end function pigs_sampler_counters16
+
+     function pigs_sampler_get_worm(ctx,isopen,iworm,xend) bind(C,name='pigs_sampler_get_worm') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int32_t) :: isopen(*),iworm(*)
+       real(c_double)     :: xend(*)
+       integer(c_int) :: rc
+     end function pigs_sampler_get_worm
+
+     function pigs_sampler_set_worm(ctx,isopen,iworm,xend) bind(C,name='pigs_sampler_set_worm') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(in) :: isopen(*),iworm(*)
+       real(c_double), intent(in)     :: xend(*)
+       integer(c_int) :: rc
+     end function pigs_sampler_set_worm
+
+     function pigs_sampler_events(ctx,events) bind(C,name='pigs_sampler_events') result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int32_t) :: events(*)
+       integer(c_int) :: rc
+     end function pigs_sampler_events
+
+     function pigs_sampler_nrho(ctx,nrho,reset) bind(C,name='pigs_sampler_nrho') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value        :: ctx
+       real(c_double)            :: nrho(*)
+       integer(c_int32_t), value :: reset
+       integer(c_int) :: rc
+     end function pigs_sampler_nrho
 
      function pigs_slice_download(ctx,ib,R) bind(C,name='pigs_slice_download') result(rc)
        import :: c_int, c_int32_t, c_double, c_ptr

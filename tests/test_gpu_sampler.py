@@ -91,3 +91,75 @@ def test_device_sampler_matches_host_sampler_counters(gpu_lib, oracle):
             subprocess.run([os.path.join(host, "pigs_vpi")], stdin=fin, stdout=fo, cwd=td, check=True, timeout=600)
         got = np.fromfile(os.path.join(td, "worldlines_final.bin")).reshape(final[0].shape)
     assert np.max(np.abs(final[0] - got)) < 1e-10
+
+
+def _run_device_worm(gpu_lib, oracle, cfg, seeds, nblock, nstep):
+    """Block loop of the reference (vpi.f90:244-545) around the device sampler with the worm sector on:
+    diagonal estimators only for walkers that end the step closed; OBDM histogram from the device."""
+    from oracle.pyoracle import System
+    S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = len(seeds)
+    ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+    ctx.sampler_init(CWorm=cfg.CWorm, swapping=cfg.swapping, Nobdm=cfg.Nobdm, Nbin=cfg.Nbin, Npw=cfg.Npw)
+    Paths, xends = [], []
+    for w, seed in enumerate(seeds):
+        P, g = oracle.init_path(S, seed)
+        Paths.append(P)
+        xends.append(np.stack([P[cfg.Nb, cfg.Np - 1], P[cfg.Nb, cfg.Np - 1]]))
+        ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+    ctx.upload_all(np.stack(Paths))
+    ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), np.stack(xends))
+    rows_e = [[] for _ in range(W)]
+    rows_t = [[] for _ in range(W)]
+    events = [[] for _ in range(W)]
+    for ib in range(nblock):
+        acc = np.zeros((W, 6))
+        nd = np.zeros(W, int)
+        for istep in range(1, nstep + 1):
+            ctx.sampler_step(istep)
+            ev = ctx.sampler_events()
+            for w in range(W):
+                events[w] += [(int(ev[w, 2 + 2 * i]), int(ev[w, 3 + 2 * i])) for i in range(ev[w, 0])]
+            closed = np.flatnonzero(ev[:, 1] == 0)
+            if len(closed):
+                E1, _, _ = ctx.local_energy_batch(0, closed)
+                E2, _, _ = ctx.local_energy_batch(2 * cfg.Nb, closed)
+                Et, Kt, Pt = ctx.therm_energy_batch(closed)
+                E = 0.5 * (E1 + E2)
+                acc[closed] += np.stack([E, E - Pt, Pt, Et, Kt, Pt], 1)
+                nd[closed] += 1
+        for w in range(W):
+            if nd[w]:
+                v = acc[w] / np.float32(nd[w]) / cfg.Np
+                rows_e[w].append([ib + 1, *v[:3]])
+                rows_t[w].append([ib + 1, *v[3:]])
+    final = ctx.download_all()
+    isopen, iworm, xend = ctx.sampler_get_worm()
+    cnt = ctx.sampler_counters16()
+    nrho = ctx.sampler_nrho()
+    ctx.close()
+    return rows_e, rows_t, final, events, cnt, (isopen, iworm, xend), nrho
+
+
+@pytest.mark.parametrize("names", [["he4_worm_s1982", "he4_worm_s1983", "he4_worm_s1984"]])
+def test_device_sampler_worm_sector_vs_reference_program(gpu_lib, oracle, names):
+    """CWorm > 0: open / close / half-chain moves / swap / OBDM on the device, against the reference
+    program's files for three seeds (block energies as printed, final worldline to rounding)."""
+    cfg = _cfg(names[0])
+    seeds = [_cfg(n).seed for n in names]
+    rows_e, rows_t, final, events, cnt, worm, nrho = _run_device_worm(gpu_lib, oracle, cfg, seeds, cfg.Nblock, cfg.Nstep)
+    assert cnt[:, 5].sum() > 0 and cnt[:, 7].sum() > 0, cnt[:, 4:8]      # opens and closes were accepted
+    for w, n in enumerate(names):
+        src = os.path.join(RUNS, n)
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        L = np.asarray(cfg.Lbox[:cfg.dim])
+        d = final[w] - want
+        d = d - L * np.round(d / L)
+        assert np.max(np.abs(d)) < 1e-9, (n, np.max(np.abs(d)))
+        e = np.atleast_2d(np.loadtxt(os.path.join(src, "e_vpi.out")))
+        et = np.atleast_2d(np.loadtxt(os.path.join(src, "et_vpi.out")))
+        got_e, got_t = np.array(rows_e[w]), np.array(rows_t[w])
+        assert got_e.shape == e.shape and np.array_equal(got_e[:, 0], e[:, 0])
+        assert np.all(np.abs(got_e[:, 1:] - e[:, 1:4]) <= 1.1e-9 * np.abs(e[:, 1:4]))
+        assert np.all(np.abs(got_t[:, 1:] - et[:, 1:4]) <= 1.1e-9 * np.abs(et[:, 1:4]))

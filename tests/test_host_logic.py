@@ -76,7 +76,7 @@ def test_derived_quantities_match_reference(name):
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "pigs_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pigs_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(pigs_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_abi_exports_every_declared_symbol():
