@@ -168,8 +168,10 @@ int pigs_sampler_set_worm(pigs_ctx *ctx, const int32_t *isopen, const int32_t *i
 /* events of the LAST step, 64 ints per walker: [0] n, [1] isopen after the step, then (code,arg) pairs in
  * order: 1 open accepted (arg iworm) 2 close accepted 3 swap accepted (arg partner) */
 int pigs_sampler_events(pigs_ctx *ctx, int32_t *events);
-/* OBDM histogram nrho(0:Npw,Nbin,w) accumulated on the device since the last reset */
-int pigs_sampler_nrho(pigs_ctx *ctx, double *nrho, int32_t reset);
+/* OBDM histogram nrho(0:Npw,Nbin,w) accumulated on the device since walker w's last reset; reset == NULL
+ * keeps everything, otherwise walker w's histogram is zeroed after the copy where reset[w] != 0 (the
+ * reference zeroes nrho only in blocks that normalise it, vpi.f90:520-532) */
+int pigs_sampler_nrho(pigs_ctx *ctx, double *nrho, const int32_t *reset);
 /* slice ib of every walker in the reference layout R(dim,Np,n_walkers) (for host-side g(r), S(k)) */
 int pigs_slice_download(pigs_ctx *ctx, int32_t ib, double *R);
 

@@ -110,7 +110,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_get_worm.argtypes = [vp, _ip, _ip, _dp]
     L.pigs_sampler_set_worm.argtypes = [vp, _ip, _ip, _dp]
     L.pigs_sampler_events.argtypes = [vp, _ip]
-    L.pigs_sampler_nrho.argtypes = [vp, _dp, C.c_int32]
+    L.pigs_sampler_nrho.argtypes = [vp, _dp, _ip]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
@@ -354,9 +354,15 @@ class PigsContext:
         _chk(self.L, self.L.pigs_sampler_events(self.h, _i(ev)), "pigs_sampler_events")
         return ev
 
-    def sampler_nrho(self, reset=False):
+    def sampler_nrho(self, reset=None):
+        """nrho[w, ibin, l]; reset: None, True (all walkers) or a per-walker mask"""
         out = np.zeros((self.n_walkers, self._nbin, self._npw + 1))
-        _chk(self.L, self.L.pigs_sampler_nrho(self.h, _d(out), int(reset)), "pigs_sampler_nrho")
+        if reset is None or reset is False:
+            keep, mask = None, None
+        else:
+            keep = np.ones(self.n_walkers, np.int32) if reset is True else _i32(reset)
+            mask = _i(keep)
+        _chk(self.L, self.L.pigs_sampler_nrho(self.h, _d(out), mask), "pigs_sampler_nrho")
         return out
 
     def slice_download(self, ib):

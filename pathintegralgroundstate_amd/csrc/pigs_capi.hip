@@ -665,12 +665,22 @@ int pigs_sampler_events(pigs_ctx *c, int32_t *events)
     return PIGS_OK;
 }
 
-int pigs_sampler_nrho(pigs_ctx *c, double *nrho, int32_t reset)
+int pigs_sampler_nrho(pigs_ctx *c, double *nrho, const int32_t *reset)
 {
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready || !nrho) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
     HIPCHK(hipMemcpyAsync(nrho, c->d_nrho, c->nrho_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (reset) HIPCHK(hipMemsetAsync(c->d_nrho, 0, c->nrho_doubles * sizeof(double), c->stream));
+    if (reset) {
+        // zero the histograms of the flagged walkers, one memset per run of consecutive walkers
+        const size_t per = c->nrho_doubles / (size_t)c->n_walkers;
+        for (int w = 0; w < c->n_walkers;) {
+            if (!reset[w]) { ++w; continue; }
+            int e = w;
+            while (e < c->n_walkers && reset[e]) ++e;
+            HIPCHK(hipMemsetAsync(c->d_nrho + (size_t)w * per, 0, (size_t)(e - w) * per * sizeof(double), c->stream));
+            w = e;
+        }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return PIGS_OK;
 }

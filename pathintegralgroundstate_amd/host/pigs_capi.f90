@@ -294,9 +294,9 @@ module pigs_capi
 
      function pigs_sampler_nrho(ctx,nrho,reset) bind(C,name='pigs_sampler_nrho') result(rc)
        import :: c_int, c_int32_t, c_double, c_ptr
-       type(c_ptr), value        :: ctx
-       real(c_double)            :: nrho(*)
-       integer(c_int32_t), value :: reset
+       type(c_ptr), value             :: ctx
+       real(c_double)                 :: nrho(*)
+       integer(c_int32_t), intent(in) :: reset(*)      ! per walker: 1 = zero the histogram after the copy
        integer(c_int) :: rc
      end function pigs_sampler_nrho
 

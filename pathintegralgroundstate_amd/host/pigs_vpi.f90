@@ -80,6 +80,8 @@ program pigs_vpi
   type(pigs_sweep_params) :: swp_par
   real(8), allocatable :: gr_inc(:,:),sk_inc(:,:,:)
   integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
+  integer(c_int32_t), allocatable :: dev_open(:),dev_iworm(:),dev_ev(:,:),dev_reset(:)
+  real(8), allocatable :: dev_nrho(:,:,:)
   character(len=32) :: suffix
 
   !---------------------------------------------------------------------
@@ -108,8 +110,8 @@ program pigs_vpi
   end if
   NW  = n_walkers
   pi = acos(-1.d0)
-  if (device_sampler .and. (CWorm/=0.d0 .or. sampling/="bis")) then
-     write (0,*) 'pigs_vpi: device_sampler = T needs CWorm = 0 and sampling = ''bis''; using the host-driven sampler'
+  if (device_sampler .and. sampling/="bis") then
+     write (0,*) 'pigs_vpi: device_sampler = T needs sampling = ''bis''; using the host-driven sampler'
      device_sampler = .false.
   end if
 
@@ -224,12 +226,17 @@ program pigs_vpi
   if (device_sampler) then
      swp_par%Nlev = Nlev; swp_par%Nstag = Nstag; swp_par%CMFreq = CMFreq; swp_par%Lstag = Lstag
      swp_par%delta_cm = delta_cm
+     swp_par%CWorm = CWorm; swp_par%density = density; swp_par%rbin = rbin
+     swp_par%swapping = merge(1,0,swapping); swp_par%Nobdm = Nobdm; swp_par%Nbin = Nbin; swp_par%Npw = Npw
      call pigs_check(pigs_sampler_init(ctx,swp_par),'pigs_sampler_init')
+     allocate (dev_open(NW),dev_iworm(NW),dev_ev(64,NW),dev_nrho(0:Npw,Nbin,NW),dev_reset(NW))
+     dev_open = merge(1,0,s%isopen); dev_iworm = s%iworm
+     call pigs_check(pigs_sampler_set_worm(ctx,dev_open,dev_iworm,s%xend),'pigs_sampler_set_worm')
      do w=1,NW
         call pigs_check(pigs_sampler_set_rng(ctx,int(w-1,c_int32_t),int(s%rng(w)%pos,c_int32_t),s%rng(w)%w), &
              & 'pigs_sampler_set_rng')
      end do
-     allocate (gr_inc(Nbin,NW),sk_inc(dim,Nk,NW),dev_acc(4,NW),dev_acc0(4,NW))
+     allocate (gr_inc(Nbin,NW),sk_inc(dim,Nk,NW),dev_acc(16,NW),dev_acc0(16,NW))
      dev_acc0 = 0
   end if
 
@@ -293,8 +300,29 @@ program pigs_vpi
         if (device_sampler) then
            ! the whole step of every walker in one launch (K6)
            call pigs_check(pigs_sampler_step(ctx,int(istep,c_int32_t)),'pigs_sampler_step')
-           if (mod(istep,CMFreq)==0) try_cm = try_cm+Np
-           try_stag = try_stag+Nstag*Np
+           if (CWorm>0.d0) then
+              ! sector of every walker after the step and what its worm did during it: the permutation-cycle
+              ! bookkeeping of the reference (sample_mod.f90:530-594) is replayed from the event log
+              call pigs_check(pigs_sampler_events(ctx,dev_ev),'pigs_sampler_events')
+              do w=1,NW
+                 s%isopen(w) = dev_ev(2,w)/=0
+                 if (swapping) then
+                    do i=1,dev_ev(1,w)
+                       select case (dev_ev(1+2*i,w))
+                       case (1)
+                          s%iworm(w) = dev_ev(2+2*i,w)
+                          perm(w)%new_cycle = .true.
+                          call perm_sampling(perm(w),.true.,s%iworm(w))
+                       case (2)
+                          perm(w)%end_cycle = .true.
+                          call perm_sampling(perm(w),.false.,s%iworm(w))
+                       case (3)
+                          call perm_sampling(perm(w),.true.,s%iworm(w),dev_ev(2+2*i,w),.true.)
+                       end select
+                    end do
+                 end if
+              end do
+           end if
         else
         ! ---- open / close attempt (reference vpi.f90:302-323)
         isopen0 = s%isopen
@@ -431,10 +459,23 @@ program pigs_vpi
 
      ! ---- end of block (reference vpi.f90:477-545)
      if (device_sampler) then
-        call pigs_check(pigs_sampler_counters(ctx,dev_acc),'pigs_sampler_counters')
-        acc_cm   = int(dev_acc(1,:)-dev_acc0(1,:)); acc_head = int(dev_acc(2,:)-dev_acc0(2,:))
-        acc_tail = int(dev_acc(3,:)-dev_acc0(3,:)); acc_bd   = int(dev_acc(4,:)-dev_acc0(4,:))
+        call pigs_check(pigs_sampler_counters16(ctx,dev_acc),'pigs_sampler_counters16')
+        dev_acc0 = dev_acc-dev_acc0
+        acc_cm   = int(dev_acc0(1,:));  acc_head  = int(dev_acc0(2,:));  acc_tail = int(dev_acc0(3,:))
+        acc_bd   = int(dev_acc0(4,:));  try_open  = int(dev_acc0(5,:));  acc_open = int(dev_acc0(6,:))
+        try_close = int(dev_acc0(7,:)); acc_close = int(dev_acc0(8,:));  acc_cm_half = int(dev_acc0(9,:))
+        acc_head_half = int(dev_acc0(10,:)); acc_tail_half = int(dev_acc0(11,:)); acc_bd_half = int(dev_acc0(12,:))
+        try_swap = int(dev_acc0(13,:)); acc_swap  = int(dev_acc0(14,:)); try_cm   = dble(dev_acc0(15,:))
+        try_stag = dble(dev_acc0(16,:))
         dev_acc0 = dev_acc
+        if (CWorm>0.d0 .and. .not. trap) then
+           ! the device keeps accumulating a walker's OBDM histogram until the block that normalises it
+           do w=1,NW
+              dev_reset(w) = merge(1,0,idiag_aux(w)/Nstep>=1)
+           end do
+           call pigs_check(pigs_sampler_nrho(ctx,dev_nrho,dev_reset),'pigs_sampler_nrho')
+           nrho = dev_nrho
+        end if
      end if
      mE = 0.d0; mT = 0.d0; nd = 0
      do w=1,NW
@@ -477,6 +518,8 @@ program pigs_vpi
               call pigs_check(pigs_sampler_get_rng(ctx,int(w-1,c_int32_t),rpos,s%rng(w)%w),'pigs_sampler_get_rng')
               s%rng(w)%pos = rpos
            end do
+           call pigs_check(pigs_sampler_get_worm(ctx,dev_open,dev_iworm,s%xend),'pigs_sampler_get_worm')
+           s%isopen = dev_open/=0; s%iworm = dev_iworm
         end if
         do w=1,NW
            suffix = ''

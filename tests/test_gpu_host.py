@@ -86,6 +86,25 @@ def test_gpu_front_end_with_device_resident_sampler(exe, tmp_path):
         assert _close(tmp_path / f"sk_vpi.w{w:04d}.out", os.path.join(src, "sk_vpi.out"), rel=1e-8)
 
 
+def test_gpu_front_end_device_sampler_worm_sector(exe, tmp_path):
+    """device_sampler = T with CWorm > 0, swapping = T: open / close / half-chain moves / swap / OBDM all on the
+    GPU; three walkers == the reference runs with seeds 1982-1984.  The permutation histogram (replayed on
+    the host from the kernel's event log) and the OBDM file must equal the reference's exactly."""
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
+    _run(exe, base + "&gpu\n n_walkers = 3, device = 0, device_sampler = T\n/\n", str(tmp_path))
+    got = np.fromfile(tmp_path / "worldlines_final.bin")
+    for w, seed in enumerate((1982, 1983, 1984)):
+        src = os.path.join(RUNS, f"he4_worm_s{seed}")
+        want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+        d = got.reshape((3,) + want.shape)[w] - want
+        assert np.mean(np.abs(d) < 1e-9) > 0.999, (w, np.max(np.abs(d)))
+        assert _close(tmp_path / f"e_vpi.w{w:04d}.out", os.path.join(src, "e_vpi.out"))
+        assert _close(tmp_path / f"et_vpi.w{w:04d}.out", os.path.join(src, "et_vpi.out"))
+        assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
+        assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / f"nr_vpi.w{w:04d}.out", "rb").read(), w
+        assert open(tmp_path / f"perm_vpi.w{w:04d}.out").read().split() == open(os.path.join(src, "fort.99")).read().split(), w
+
+
 def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     """device_sampler = T: 4 blocks in one go == 2 blocks + resume for 2 more; exercises the block-form
     generator snapshot the sampler kernel keeps for checkpoints (pigs_sampler_get_rng)."""
