@@ -23,7 +23,11 @@ def main():
         Paths, _ = make_workload(cfg, W, 1, 1982)
         ctx = api.PigsContext(cfg, VT, WF, n_walkers=W)
         ctx.upload_all(Paths)
-        ctx.sampler_init()
+        cworm = float(os.environ.get('CWORM', 0))
+        ctx.sampler_init(CWorm=cworm, swapping=cworm > 0, Nobdm=int(os.environ.get('NOBDM', 10)))
+        if cworm > 0:       # every walker starts closed; xend = bead Nb of the last particle, like the reference's init
+            xe = np.repeat(Paths[:, cfg.Nb, cfg.Np - 1][:, None, :], 2, axis=1)
+            ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe)
         if os.environ.get('SWEEP_DEBUG'):
             ctx.set_tuning('sweep_debug', int(os.environ['SWEEP_DEBUG']))
         if os.environ.get('SWEEP_THREADS'):
@@ -38,6 +42,10 @@ def main():
         ctx.sync()
         dt = (time.perf_counter() - t0) / nsteps
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
+        if cworm > 0:
+            c16 = ctx.sampler_counters16().sum(0)
+            print(f"   worm: open {c16[5]}/{c16[4]}, close {c16[7]}/{c16[6]}, swap {c16[13]}/{c16[12]}, "
+                  f"open walkers now {int(ctx.sampler_get_worm()[0].sum())}", flush=True)
         t1 = time.perf_counter()
         E, Ec, Ep = ctx.therm_energy_batch()
         t2 = time.perf_counter()
