@@ -132,8 +132,9 @@ int pigs_commit_beads(pigs_ctx *ctx, int64_t n, const int32_t *walker, const int
 /* Swap accept branch, vpi_mod.f90:2454-2464: exchange beads Nb..2Nb of particles iw, ik. */
 int pigs_swap_tails(pigs_ctx *ctx, int32_t walker, int32_t iw, int32_t ik);
 
-/* ---- K6: device-resident sampler (diagonal sector, sampling='bis'; reference vpi.f90:297-439
- * with the movers TranslateChain, MoveHeadBisection, MoveTailBisection, Bisection of vpi_mod.f90).
+/* ---- K6: device-resident sampler (reference vpi.f90:297-439 with the movers TranslateChain and
+ * MoveHeadBisection, MoveTailBisection, Bisection (sampling='bis') or MoveHead, MoveTail, Staging
+ * (sampling='sta') of vpi_mod.f90).
  * One launch advances EVERY resident walker by one MC step with no host round trip: random
  * numbers (each walker's own MT19937 stream, identical to the reference's for its seed),
  * proposals, Delta S, Metropolis and commit all run on the GPU.  With CWorm > 0 the worm sector is
@@ -146,6 +147,7 @@ typedef struct pigs_sweep_params {
     /* worm sector (namelist obdm); CWorm = 0 keeps every walker in the diagonal sector */
     double  CWorm, density, rbin;         /* rbin = rcut/real(Nbin) (vpi.f90:128), for the OBDM histogram     */
     int32_t swapping, Nobdm, Nbin, Npw;
+    int32_t sampling, reserved;           /* diagonal movers: 0 = 'bis' (bisection), 1 = 'sta' (staging) */
 } pigs_sweep_params;
 int pigs_sampler_init(pigs_ctx *ctx, const pigs_sweep_params *sp);
 /* seed walker's stream as the reference's sgrnd(seed) does */

@@ -47,7 +47,8 @@ class PigsError(RuntimeError):
 class PigsSweepParams(C.Structure):
     _fields_ = [("Nlev", C.c_int32), ("Nstag", C.c_int32), ("CMFreq", C.c_int32), ("Lstag", C.c_int32),
                 ("delta_cm", C.c_double), ("CWorm", C.c_double), ("density", C.c_double), ("rbin", C.c_double),
-                ("swapping", C.c_int32), ("Nobdm", C.c_int32), ("Nbin", C.c_int32), ("Npw", C.c_int32)]
+                ("swapping", C.c_int32), ("Nobdm", C.c_int32), ("Nbin", C.c_int32), ("Npw", C.c_int32),
+                ("sampling", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PigsParams(C.Structure):
@@ -301,14 +302,15 @@ class PigsContext:
 
     # ---- K6: device-resident sampler
     def sampler_init(self, Nlev=None, Nstag=None, CMFreq=None, Lstag=None, delta_cm=None, CWorm=0.0,
-                     swapping=False, Nobdm=0, Nbin=None, Npw=0):
+                     swapping=False, Nobdm=0, Nbin=None, Npw=0, sampling="bis"):
         c = self.cfg
         self._nbin = c.Nbin if Nbin is None else Nbin
         self._npw = Npw
         sp = PigsSweepParams(c.Nlev if Nlev is None else Nlev, c.Nstag if Nstag is None else Nstag,
                              c.CMFreq if CMFreq is None else CMFreq, c.Lstag if Lstag is None else Lstag,
                              c.delta_cm_eff if delta_cm is None else delta_cm, CWorm, c.density,
-                             c.rcut / float(np.float32(self._nbin)), int(swapping), Nobdm, self._nbin, Npw)
+                             c.rcut / float(np.float32(self._nbin)), int(swapping), Nobdm, self._nbin, Npw,
+                             {"bis": 0, "sta": 1}[sampling], 0)
         _chk(self.L, self.L.pigs_sampler_init(self.h, C.byref(sp)), "pigs_sampler_init")
 
     def sampler_seed(self, walker, seed):

@@ -508,7 +508,9 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
 {
     int rc = check_ctx(c); if (rc) return rc;
     if (!sp) return fail(PIGS_ERR_ARG, "null sweep params");
-    if (sp->Nlev < 1 || (1 << sp->Nlev) > 16 || (1 << sp->Nlev) > 2 * c->P.Nb || sp->Nstag < 0 || sp->CMFreq < 1 ||
+    const bool sta = sp->sampling == 1;
+    if (sp->sampling != 0 && sp->sampling != 1) return fail(PIGS_ERR_ARG, "sampling must be 0 ('bis') or 1 ('sta')");
+    if ((!sta && (sp->Nlev < 1 || (1 << sp->Nlev) > 16 || (1 << sp->Nlev) > 2 * c->P.Nb)) || sp->Nstag < 0 || sp->CMFreq < 1 ||
         sp->Lstag < 2 || sp->Lstag > c->P.Nb)
         return fail(PIGS_ERR_ARG, "sweep params out of range (Nlev=%d Nstag=%d CMFreq=%d Lstag=%d)", sp->Nlev, sp->Nstag, sp->CMFreq, sp->Lstag);
     const bool worm = sp->CWorm > 0.0;
@@ -517,7 +519,7 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     if (worm && 2 + 2 * (1 + sp->Nobdm) > kEvInts) return fail(PIGS_ERR_UNSUPPORTED, "Nobdm=%d exceeds the event log", sp->Nobdm);
     SweepParams &k = c->sweep;
     memset(&k, 0, sizeof k);
-    k.Nlev = sp->Nlev; k.Nstag = sp->Nstag; k.Lstag = sp->Lstag;
+    k.Nlev = sta ? 1 : sp->Nlev; k.Nstag = sp->Nstag; k.Lstag = sp->Lstag; k.staging = sta;
     k.delta_cm = sp->delta_cm; k.open_attempt = 1; k.do_cm = 1;
     k.worm = worm; k.swapping = sp->swapping != 0; k.Nobdm = worm ? sp->Nobdm : 0;
     k.Nbin = worm ? sp->Nbin : 1; k.Npw = worm ? sp->Npw : 0; k.rbin = worm ? sp->rbin : 1.0;

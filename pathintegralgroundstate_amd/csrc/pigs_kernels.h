@@ -54,7 +54,7 @@ constexpr int kEvInts = 64;         // event log of one MC step
 struct SweepParams {
     int32_t Nlev, Nstag, Lstag, do_cm;
     int32_t open_attempt, pad0, worm, swapping;   // worm: CWorm > 0 (open/close/swap sector sampled)
-    int32_t Nobdm, Nbin, Npw, pad3;
+    int32_t Nobdm, Nbin, Npw, staging;            // staging: sampling = 'sta' in the diagonal sector
     double  delta_cm, log_cworm_density, rbin;
 };
 hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,

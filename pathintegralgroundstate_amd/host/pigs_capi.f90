@@ -23,6 +23,7 @@ module pigs_capi
      real(c_double)     :: delta_cm
      real(c_double)     :: CWorm, density, rbin
      integer(c_int32_t) :: swapping, Nobdm, Nbin, Npw
+     integer(c_int32_t) :: sampling = 0, reserved = 0      ! 0 = 'bis', 1 = 'sta'
   end type pigs_sweep_params
 
   type, bind(C) :: pigs_params

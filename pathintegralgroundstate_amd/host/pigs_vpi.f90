@@ -110,8 +110,8 @@ program pigs_vpi
   end if
   NW  = n_walkers
   pi = acos(-1.d0)
-  if (device_sampler .and. sampling/="bis") then
-     write (0,*) 'pigs_vpi: device_sampler = T needs sampling = ''bis''; using the host-driven sampler'
+  if (device_sampler .and. Lstag>Nb) then
+     write (0,*) 'pigs_vpi: device_sampler = T needs Lstag <= Nb; using the host-driven sampler'
      device_sampler = .false.
   end if
 
@@ -227,6 +227,7 @@ program pigs_vpi
      swp_par%Nlev = Nlev; swp_par%Nstag = Nstag; swp_par%CMFreq = CMFreq; swp_par%Lstag = Lstag
      swp_par%delta_cm = delta_cm
      swp_par%CWorm = CWorm; swp_par%density = density; swp_par%rbin = rbin
+     swp_par%sampling = merge(1,0,sampling=="sta")
      swp_par%swapping = merge(1,0,swapping); swp_par%Nobdm = Nobdm; swp_par%Nbin = Nbin; swp_par%Npw = Npw
      call pigs_check(pigs_sampler_init(ctx,swp_par),'pigs_sampler_init')
      allocate (dev_open(NW),dev_iworm(NW),dev_ev(64,NW),dev_nrho(0:Npw,Nbin,NW),dev_reset(NW))

@@ -105,6 +105,24 @@ def test_gpu_front_end_device_sampler_worm_sector(exe, tmp_path):
         assert open(tmp_path / f"perm_vpi.w{w:04d}.out").read().split() == open(os.path.join(src, "fort.99")).read().split(), w
 
 
+@pytest.mark.parametrize("name", ["he4_cworm0", "ho1d_n2"])
+def test_gpu_front_end_device_sampler_staging_movers(exe, name, tmp_path):
+    """device_sampler = T with sampling = 'sta' (MoveHead, MoveTail, Staging on the GPU): the 2D periodic run with
+    CWorm = 0 and the 1D trapped N=2 run with worm + swap (quirk Q9) against the reference program's files."""
+    src = os.path.join(RUNS, name)
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = T\n/\n",
+         str(tmp_path))
+    assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert np.mean(np.abs(got - want) < 1e-9) > 0.999, np.max(np.abs(got - want))
+    for f in ("e_vpi.out", "et_vpi.out"):
+        assert _close(tmp_path / f, os.path.join(src, f)), f
+    if os.path.exists(os.path.join(src, "nr_vpi.out")):
+        assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+    assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
+
+
 def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     """device_sampler = T: 4 blocks in one go == 2 blocks + resume for 2 more; exercises the block-form
     generator snapshot the sampler kernel keeps for checkpoints (pigs_sampler_get_rng)."""
