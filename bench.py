@@ -238,12 +238,32 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             mc_el = float(tt.item())
         acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 1))
+        # the same steps followed by the diagonal-sector estimators of vpi.f90:443-469 (2 x LocalEnergy K4,
+        # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker: SURVEY 8d's definition of a sweep
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for i in range(nmc):
+            ctx.sampler_step(2 + nmc + i)
+            ctx.local_energy_batch(0)
+            ctx.local_energy_batch(2 * cfg.Nb)
+            ctx.therm_energy_batch()
+            ctx.structure_batch(cfg.Nb, 100, cfg.rcut / 100.0, 50)
+        ctx.sync()
+        mc_full = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([mc_full], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mc_full = float(tt.item())
         # Delta-S items of one sweep of one walker: Np*(2Nb+1) + the bisection stages actually run;
         # the exact count depends on early exits, so it is bounded by SURVEY 8d's schedule
-        mc = {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc,
-              "walkers_per_gpu": W, "kernel": "pigs::k_sweep (one launch per MC step)",
+        mc = {"walker_sweeps_per_s": world * W * nmc / mc_full, "ms_per_mc_step": 1e3 * mc_full / nmc,
+              "moves_only": {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc},
+              "walkers_per_gpu": W,
+              "kernels": "pigs::k_sweep (one launch per MC step: all moves) + k_local_energy x2, k_slice_energy, "
+                         "k_therm_combine, k_structure per step",
               "accepted_moves_per_sweep_per_walker": {"cm": acc[0], "head": acc[1], "tail": acc[2], "bisection": acc[3]},
-              "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in)",
+              "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in), estimators every step",
               "reference_cpu_sweeps_per_s_per_core": 1.24}
     except api.PigsError as exc:       # pragma: no cover
         mc = {"error": str(exc)}

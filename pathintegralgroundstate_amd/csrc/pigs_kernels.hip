@@ -16,10 +16,13 @@ namespace pigs {
 
 // =====================================================================================
 // K2 (+K3): one workgroup per (walker, slice).  The slice is staged once in LDS (SoA);
-// thread i owns particle i and walks every partner j != i (LDS broadcast reads), so the
-// full force vector F_i stays in registers and no antisymmetric scatter / atomics are
-// needed.  Each pair is visited from both sides: V counts half from each side
-// (multiplying by 0.5 is exact), f_ji = -f_ij exactly (the wrap is odd-symmetric).
+// thread i owns particle i.  Slices that need forces (odd beads): it walks every partner j != i
+// (LDS broadcast reads), so the full force vector F_i stays in registers, summed in the
+// reference's partner order, and no antisymmetric scatter / atomics are needed; each pair is
+// visited from both sides, V counts half from each side (multiplying by 0.5 is exact), f_ji = -f_ij
+// exactly (the wrap is odd-symmetric).  Slices that need V only (even beads): each pair once,
+// thread i taking the next floor(Np/2) partners around the ring.  sqrt and the quotients use the
+// exact few-instruction forms of pigs_device.h (same bits as `sqrt` and `/`).
 // Optional spring term of ThermEnergy between slice ib and ib+1 (sample_mod.f90:359-380).
 // out[3*slot+0..2] = Pot, F2 (0 if !want_f2), spring sum.
 // =====================================================================================
@@ -58,14 +61,14 @@ __global__ __launch_bounds__(256) void k_slice_energy(
                 pot  = pot + trap_pot(0, P.a_ho[k], xi[k]);
             }
         }
-        for (int j = 0; j < P.Np; ++j) {
-            if (j == i) continue;
-            double d[DIM];
+        if (TRAP) {
+            for (int j = 0; j < P.Np; ++j) {
+                if (j == i) continue;
+                double d[DIM];
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];   // :51
-            const double r2 = TRAP ? plain_r2<DIM>(d) : min_image<DIM>(d, P);
-            if (TRAP || r2 <= P.rcut2) {                      // :64 / :98
-                const double r = sqrt(r2);
+                for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];   // :51
+                const double r2 = plain_r2<DIM>(d);
+                const double r = sqrt(r2);                        // no cutoff in the trap (:64)
                 const Lerp L = lerp_setup(r, P.dr, P.Nmax);
                 poti = poti + interp0(VT, L, P.dr);
                 if (want_f) {
@@ -74,8 +77,44 @@ __global__ __launch_bounds__(256) void k_slice_energy(
                     for (int k = 0; k < DIM; ++k) F[k] = F[k] + dv * d[k] / r;  // :113-114
                 }
             }
+            poti = 0.5 * poti;
+        } else if (want_f) {
+            // odd slice: every partner, so that F_i is summed in the reference's partner order
+            for (int j = 0; j < P.Np; ++j) {
+                if (j == i) continue;
+                double d[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
+                const double r2 = min_image_fast<DIM>(d, P);
+                if (r2 <= P.rcut2) {                              // :98
+                    double r, rinv, v, dv;
+                    sqrt_rinv(r2, r, rinv);                       // exact sqrt and quotients (pigs_device.h)
+                    const FLerp L = flerp_setup(r, P);
+                    finterp01(VT, L, P, v, dv);
+                    poti = poti + v;
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) F[k] = F[k] + div_by(dv * d[k], r, rinv);
+                }
+            }
+            poti = 0.5 * poti;
+        } else {
+            // even slice: V only, each pair once -- thread i takes the next floor(Np/2) partners around the
+            // ring (for even Np the opposite partner belongs to the lower half of the ring only)
+            const int h = (P.Np & 1) ? (P.Np - 1) / 2 : (i < P.Np / 2 ? P.Np / 2 : P.Np / 2 - 1);
+            int j = i;
+            for (int q = 0; q < h; ++q) {
+                j = j + 1 == P.Np ? 0 : j + 1;
+                double d[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
+                const double r2 = min_image_fast<DIM>(d, P);
+                if (r2 <= P.rcut2) {
+                    const FLerp L = flerp_setup(sqrt_exact(r2), P);
+                    poti = poti + finterp0(VT, L, P);
+                }
+            }
         }
-        pot = pot + 0.5 * poti;
+        pot = pot + poti;
         if (want_f) {
 #pragma unroll
             for (int k = 0; k < DIM; ++k) f2 = f2 + F[k] * F[k];                // :143
