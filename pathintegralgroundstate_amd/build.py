@@ -36,7 +36,8 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include")] + \
+    extra = os.environ.get("PIGS_EXTRA_FLAGS", "").split()          # experiment builds (e.g. -DPIGS_SWEEP_TIMING)
+    cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include")] + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))

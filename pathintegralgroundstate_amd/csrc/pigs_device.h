@@ -167,6 +167,9 @@ __device__ __forceinline__ FLerp flerp_setup(double x, const DevParams &P)
     L.a1  = x - (double)(ix - 1) * P.dr;
     L.a2  = P.dr - L.a1;
     L.ix  = min(ix, P.Nmax);
+#ifdef PIGS_EXPERIMENT_HOT_TABLE
+    L.ix  = (L.ix & 63) + 2;                 // timing experiment only: every lookup hits the same few lines
+#endif
     L.im2 = max(L.ix - 2, 0);
     return L;
 }

@@ -42,6 +42,10 @@ def main():
         ctx.sync()
         dt = (time.perf_counter() - t0) / nsteps
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
+        if os.environ.get('TIMING'):     # library built with PIGS_EXTRA_FLAGS=-DPIGS_SWEEP_TIMING
+            c16 = ctx.sampler_counters16()[:, 8:].mean(0) / (nsteps + 1)
+            names = ['A gen(seg,end)', 'A sync', 'B end eval', 'B end metro+sync', 'C level gen', 'C sync', 'D level eval', 'E level metro+sync']
+            print('   shader-clock cycles per MC step per walker (thread 0): ' + ', '.join(f'{n} {v / 1e3:.0f}k' for n, v in zip(names, c16)), flush=True)
         if cworm > 0:
             c16 = ctx.sampler_counters16().sum(0)
             print(f"   worm: open {c16[5]}/{c16[4]}, close {c16[7]}/{c16[6]}, swap {c16[13]}/{c16[12]}, "
