@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
+from helpers import same_bits
 from pathintegralgroundstate_amd import SystemConfig
 
 pytestmark = pytest.mark.gpu
@@ -163,3 +164,48 @@ def test_device_sampler_worm_sector_vs_reference_program(gpu_lib, oracle, names)
         assert got_e.shape == e.shape and np.array_equal(got_e[:, 0], e[:, 0])
         assert np.all(np.abs(got_e[:, 1:] - e[:, 1:4]) <= 1.1e-9 * np.abs(e[:, 1:4]))
         assert np.all(np.abs(got_t[:, 1:] - et[:, 1:4]) <= 1.1e-9 * np.abs(et[:, 1:4]))
+
+
+def test_worm_bookkeeping_entry_points(gpu_lib, oracle):
+    """pigs_sampler_nrho's per-walker reset, the event log layout and the worm state round trip."""
+    cfg = _cfg("he4_worm_s1982")
+    from oracle.pyoracle import System
+    S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = 4
+    ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+    ctx.sampler_init(CWorm=cfg.CWorm, swapping=True, Nobdm=cfg.Nobdm, Nbin=cfg.Nbin, Npw=1)
+    Paths = []
+    for w in range(W):
+        P, g = oracle.init_path(S, 100 + w)
+        Paths.append(P)
+        ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+    Paths = np.stack(Paths)
+    ctx.upload_all(Paths)
+    xe = np.repeat(Paths[:, cfg.Nb, cfg.Np - 1][:, None, :], 2, axis=1)
+    ctx.sampler_set_worm(np.zeros(W, np.int32), np.arange(1, W + 1, dtype=np.int32), xe)
+    o, iw, x = ctx.sampler_get_worm()
+    assert not o.any() and np.array_equal(iw, np.arange(1, W + 1)) and same_bits(x, xe)
+    n_open_steps = np.zeros(W, int)
+    for istep in range(1, 61):
+        ctx.sampler_step(istep)
+        ev = ctx.sampler_events()
+        assert np.all(ev[:, 0] >= 0) and np.all(ev[:, 0] <= 1 + cfg.Nobdm) and set(np.unique(ev[:, 1])) <= {0, 1}
+        for w in range(W):
+            codes = ev[w, 2:2 + 2 * ev[w, 0]:2]
+            assert set(codes.tolist()) <= {1, 2, 3}
+        n_open_steps += ev[:, 1]
+    assert n_open_steps.sum() > 0
+    h = ctx.sampler_nrho()
+    # every step spent open adds Nobdm end-to-end vectors inside the cutoff at most, with weight 1 in the l=0 column
+    assert np.all(h[:, :, 0].sum(1) <= n_open_steps * cfg.Nobdm + 1e-9) and h[:, :, 0].sum() > 0
+    assert np.array_equal(h[:, :, 0], np.round(h[:, :, 0]))
+    mask = np.array([1, 0, 1, 0], np.int32)
+    h2 = ctx.sampler_nrho(reset=mask)
+    assert same_bits(h, h2)
+    h3 = ctx.sampler_nrho()
+    assert not h3[0].any() and not h3[2].any() and same_bits(h3[1], h[1]) and same_bits(h3[3], h[3])
+    c = ctx.sampler_counters16()
+    assert np.all(c[:, 5] <= c[:, 4]) and np.all(c[:, 7] <= c[:, 6]) and np.all(c[:, 13] <= c[:, 12])
+    assert np.all(c[:, 14] <= 60 * cfg.Np) and np.all(c[:, 15] <= 60 * cfg.Nstag * cfg.Np)
+    ctx.close()
