@@ -164,9 +164,11 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     P.trap = p->trap; P.wf_table = p->wf_table; P.v_table = p->v_table; P.nW = n_walkers;
     P.dr = p->dr; P.rcut2 = p->rcut2; P.dt = p->dt; P.Rm = p->Rm;
     P.rdr = 1.0 / p->dr;                               // correctly rounded reciprocal (div_by)
+    P.hrdr = 0.5 * P.rdr;
     for (int k = 0; k < 3; ++k) {
         P.Lbox[k]     = k < p->dim ? p->Lbox[k] : 1.0;
         P.LboxHalf[k] = 0.5 * P.Lbox[k];                 // vpi.f90:118
+        P.rLbox[k]    = 1.0 / P.Lbox[k];
         P.a_ho[k]     = k < p->dim ? p->a_ho[k] : 1.0;
     }
     c->path_doubles = slice_doubles(P.dim, P.NpPad) * P.M;
@@ -235,7 +237,7 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
 {
     if (!c || !key) return fail(PIGS_ERR_ARG, "null pointer");
     if (!strcmp(key, "k1_variant")) {
-        if (value < K1_AUTO || value > K1_V2_PREFETCH) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
+        if (value < K1_AUTO || value > K1_PIPE) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
         c->k1_variant = value;
         return PIGS_OK;
     }

@@ -26,6 +26,8 @@ struct DevParams {
     double  dr, rcut2, dt, Rm;
     double  Lbox[3], LboxHalf[3], a_ho[3];
     double  rdr;                         // RN(1/dr), for the exact constant division below
+    double  hrdr;                        // 0.5/dr and 1/L: the short-arithmetic path (pigs_k1_device.h, FastTab)
+    double  rLbox[3];
 };
 
 // Resident worldline layout in HBM ("bead-major, SoA inside a slice"):
@@ -206,6 +208,63 @@ __device__ __forceinline__ double min_image_fast(double (&x)[DIM], const DevPara
         r2 = r2 + u * u;
     }
     return r2;
+}
+
+// ---- short-arithmetic forms (K1 variant "fast", selected by passing the table as a FastTab) ----
+// Same quantities as above to ~1 ulp per term instead of the reference's exact rounding sequence:
+//   * minimum image as v - L*rint(v/L): identical result to the two compares except for |v| within an
+//     ulp of L/2 exactly, where the pair is outside the cutoff anyway (r >= L/2 >= rcut);
+//   * r^2 keeps the reference's rounding sequence, so the cutoff decision r2 <= rcut2 is unchanged;
+//   * sqrt / 1/r from one v_rsq_f64 + one coupled Newton step (r to < 1 ulp, 1/r to ~1e-14);
+//   * interpolation in the normalised cell coordinate f = r/dr - int(r/dr): f*F[i+1] + (1-f)*F[i]
+//     instead of (a1*F(ix) + a2*F(ix-1))/dx -- the same straight line, rounded differently.
+// ~50 fp64-rate instructions per in-cutoff distance on odd beads instead of ~105.
+struct FastTab {
+    const double *p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+template <typename T> struct is_fast_tab { static constexpr bool value = false; };
+template <> struct is_fast_tab<FastTab> { static constexpr bool value = true; };
+
+template <int DIM>
+__device__ __forceinline__ double min_image_rn(double (&x)[DIM], const DevParams &P)
+{
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const double v = x[k];
+        const double n = __builtin_rint(v * P.rLbox[k]);
+        const double u = __builtin_fma(-P.Lbox[k], n, v);
+        x[k] = u;
+        r2 = r2 + u * u;                                          // the reference's rounding sequence
+    }
+    return r2;
+}
+
+struct FCell {
+    int    i0;        // int(r/dr) = ix-1 of the reference
+    double f, omf;    // position inside the cell, 1-f
+    double r, rinv;
+};
+
+__device__ __forceinline__ FCell fcell_setup(double r2, const DevParams &P)
+{
+    FCell C;
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    double g = r2 * y0;
+    double h = 0.5 * y0;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    const double d0 = __builtin_fma(-g, g, r2);
+    g = __builtin_fma(d0, h, g);
+    C.r    = g;
+    C.rinv = h + h;
+    const double t = g * P.rdr;
+    C.i0  = (int)t;
+    C.f   = t - (double)C.i0;
+    C.omf = 1.0 - C.f;
+    return C;
 }
 
 // ---- several accumulators reduced over the wave with one shared butterfly: at each of the

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 // =====================================================================================
 // LDS layout (dynamic): [VTable copy: Nmax+2 doubles, if LDSTAB][per wave: kWaveLds bytes = reduction
 // scratch (8 x 65 doubles), whose head doubles as the 512 x u16 code list of COMPACT]
-template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK, bool PREFETCH = false>
+template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK, bool PREFETCH = false, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
     DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
     const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
@@ -217,11 +217,161 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
             if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
             else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
             else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
+        } else if (FAST && !TRAP) {                             // short arithmetic (pigs_device.h, FastTab)
+            if (PREFETCH) item_eval_prefetch<DIM, TRAP>(P, FastTab{VT}, WF, S, p, b, xn, xo, lane, red, o, q);
+            else          item_eval<DIM, TRAP>(P, FastTab{VT}, WF, S, p, b, xn, xo, lane, red, o, q);
         } else if (PREFETCH) {
             item_eval_prefetch<DIM, TRAP>(P, VT, WF, S, p, b, xn, xo, lane, red, o, q);
         } else {
             item_eval<DIM, TRAP>(P, VT, WF, S, p, b, xn, xo, lane, red, o, q);
         }
+    }
+}
+
+// =====================================================================================
+// K1 "pipe": the short-arithmetic item evaluation as a persistent, software-pipelined kernel
+// (PBC, Np <= 256).  One 1024-thread workgroup per CU keeps the VTable in LDS -- the table gather was
+// what kept the texture addresser 60-65 % busy in v2 and held every wave on s_waitcnt -- and every
+// wave requests an item's partner coordinates (4 passes x DIM loads) up front and evaluates the two
+// distances of a pass as branch-free, independent chains (masked lanes enter the sums with weight 0);
+// LDS gathers count on lgkmcnt, so they never wait for outstanding global loads; the waves of a workgroup
+// draw its items from an LDS counter (odd beads cost twice the even ones).  Measured and dropped: a rolling
+// two-pass lookahead into the NEXT item's slice and vector-loaded item records (both slower).
+// =====================================================================================
+template <int DIM>
+struct ItemRec {
+    int    p, b, ok;                       // wave-uniform
+    double xn[DIM], xo[DIM];
+    double rj[4][DIM];                     // partner coordinates of the four passes
+};
+
+template <int DIM>
+__device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__restrict__ paths, int it,
+                                           const int32_t *__restrict__ walker, const int32_t *__restrict__ ipv,
+                                           const int32_t *__restrict__ ibv, const double *__restrict__ xnew,
+                                           const double *__restrict__ xold, int lane, size_t sl, ItemRec<DIM> &R)
+{
+    const int w = walker[it];
+    R.p = ipv[it] - 1;
+    R.b = ibv[it];
+    R.ok = (unsigned)w < (unsigned)P.nW && (unsigned)R.p < (unsigned)P.Np && (unsigned)R.b < (unsigned)P.M;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        R.xn[k] = xnew[(size_t)it * DIM + k];
+        R.xo[k] = xold[(size_t)it * DIM + k];
+    }
+    const double *S = paths + (R.ok ? ((size_t)w * P.M + R.b) * sl : 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j  = m * kWave + lane;
+        const int jj = j < P.Np ? j : 0;                              // in-bounds dummy for idle lanes
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) R.rj[m][k] = S[(size_t)k * P.NpPad + jj];
+    }
+}
+
+// one distance, branch-free: lanes outside the cutoff (or without a partner) evaluate the cell of rcut and
+// enter the sums with weight 0 through the accumulating fma (fma(v, 1, acc) rounds like acc + v), so the new
+// and the old distance are independent straight-line chains the scheduler interleaves
+template <int DIM, int CLS, bool IS_OLD>
+__device__ __forceinline__ void pipe_pair(const DevParams &P, FastTab VT, const double *__restrict__ WF,
+                                          double r2, bool in, const double (&d)[DIM], Acc<DIM, CLS> &A)
+{
+    const double wgt = in ? 1.0 : 0.0;
+    const FCell C = fcell_setup(in ? r2 : P.rcut2, P);
+    const double *V = VT.p + C.i0;
+    const double F0 = V[0], F1 = V[1];
+    const double v = __builtin_fma(C.f, F1, C.omf * F0);
+    if (IS_OLD) A.potO = __builtin_fma(v, wgt, A.potO); else A.potN = __builtin_fma(v, wgt, A.potN);
+    if (CLS == CLS_ODD) {
+        const double Fm = VT.p[max(C.i0 - 1, 0)], Fp = V[2];
+        const double Fb = __builtin_fma(C.f, F0, C.omf * Fm);
+        const double Fa = __builtin_fma(C.f, Fp, C.omf * F1);
+        const double s  = (((Fa - Fb) * P.hrdr) * C.rinv) * wgt;       // (dV/dr)/r
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            if (IS_OLD) A.fO[k] = __builtin_fma(s, d[k], A.fO[k]); else A.fN[k] = __builtin_fma(s, d[k], A.fN[k]);
+        }
+    }
+    if (CLS == CLS_END) {
+        const double *U = WF + C.i0;
+        const double u = __builtin_fma(C.f, U[1], C.omf * U[0]);
+        if (IS_OLD) A.psiO = __builtin_fma(u, wgt, A.psiO); else A.psiN = __builtin_fma(u, wgt, A.psiN);
+    }
+}
+
+template <int DIM, int CLS>
+__device__ __forceinline__ void pipe_item(const DevParams &P, FastTab VT, const double *__restrict__ WF,
+                                          const ItemRec<DIM> &R, int lane, double *red, double *out, double *parts)
+{
+    Acc<DIM, CLS> A;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = m * kWave + lane;
+        const bool valid = j < P.Np && j != R.p;                      // row p itself never enters (vpi_mod.f90:2699)
+        double dn[DIM], dold[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            // opaque per (class, pass): keeps the optimiser from hoisting the distance arithmetic of all four
+            // passes above the class branch (it did: 24 live doubles more, spills)
+            double rj = R.rj[m][k];
+            asm volatile("; class %1 pass" : "+v"(rj) : "n"(CLS));
+            dn[k] = R.xn[k] - rj; dold[k] = R.xo[k] - rj;
+        }
+        const double r2o = min_image_rn<DIM>(dold, P);
+        const double r2n = min_image_rn<DIM>(dn, P);
+        pipe_pair<DIM, CLS, false>(P, VT, WF, r2n, valid && r2n <= P.rcut2, dn, A);
+        pipe_pair<DIM, CLS, true>(P, VT, WF, r2o, valid && r2o <= P.rcut2, dold, A);
+        __builtin_amdgcn_sched_barrier(0);                            // two chains in flight, not eight (VGPRs)
+    }
+    finish_item<DIM, CLS>(P, lane, R.b, A, red, out, parts);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(1024) void k_delta_action_pipe(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int next_local;                                  // this workgroup's item queue
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+
+    double *tab = reinterpret_cast<double *>(smem);
+    const int nt = P.Nmax + 2;
+    for (int t = threadIdx.x; t < nt; t += 1024) tab[t] = VTg[t];
+    if (threadIdx.x == 0) next_local = 16;
+    const size_t off = ((size_t)nt * sizeof(double) + 15) & ~(size_t)15;
+    double *red = reinterpret_cast<double *>(smem + off + (size_t)wid * kWaveLds);
+    __syncthreads();                                            // the only workgroup barrier
+    const FastTab VT{tab};
+
+    // Items blockIdx.x + k*gridDim.x belong to this workgroup (consecutive items -- one walker's beads, odd and
+    // even ones costing 2:1 -- spread over all CUs); its 16 waves take them from an LDS counter as they
+    // become free, so no wave idles behind a neighbour that drew the expensive items.
+    const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int k = wid; k < n_local;) {
+        const int it = (int)blockIdx.x + k * (int)gridDim.x;
+        ItemRec<DIM> cur;
+        pipe_fetch<DIM>(P, paths, it, walker, ipv, ibv, xnew, xold, lane, sl, cur);
+        int kn = 0;
+        if (lane == 0) kn = atomicAdd(&next_local, 1);
+        k = __builtin_amdgcn_readfirstlane(kn);
+        double *o = out + it;
+        double *q = parts ? parts + (size_t)it * 3 : nullptr;
+        if (!cur.ok) {
+            if (lane == 0) *o = __builtin_nan("");
+            continue;
+        }
+        const bool odd  = (cur.b & 1) != 0;
+        const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
+        if (odd)       pipe_item<DIM, CLS_ODD>(P, VT, WF, cur, lane, red, o, q);
+        else if (endb) pipe_item<DIM, CLS_END>(P, VT, WF, cur, lane, red, o, q);
+        else           pipe_item<DIM, CLS_EVEN>(P, VT, WF, cur, lane, red, o, q);
     }
 }
 
@@ -270,6 +420,21 @@ static int k1_grid(int n_items, int waves_per_block, int cap_blocks)
     return blocks < cap_blocks ? (blocks > 0 ? blocks : 1) : cap_blocks;
 }
 
+// persistent grid of the pipelined kernel: one 1024-thread workgroup per CU
+static int k1_pipe_blocks()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            n = pr.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 template <typename K>
 static hipError_t set_lds(K kern, size_t bytes)
 {
@@ -290,6 +455,10 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
     if ((variant == K1_V2_LDS || variant == K1_V2_LDS_COMPACT) && !can_ldstab) variant = K1_V2;
     if (variant == K1_V2_PREFETCH && P.Np > 256) variant = K1_V2;
+    if (variant == K1_FAST_PREFETCH && P.Np > 256) variant = K1_FAST;
+    if ((variant == K1_FAST_LDS || variant == K1_FAST_LDS_PREFETCH) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
+    if (variant == K1_PIPE && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
+    if (variant >= K1_FAST && P.trap) variant = K1_V2;   // no cutoff in the trap: exact path
     hipError_t e = hipSuccess;
     switch (variant) {
     case K1_V1: {
@@ -318,6 +487,24 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
 #undef CALL
         break;
     }
+    case K1_FAST: {
+        const size_t lds = 4 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, false, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
+                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_FAST_PREFETCH: {
+        const size_t lds = 4 * kWaveLds;
+#define CALL(D, T)                                                                                      \
+    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, true, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
+                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
     case K1_V2_COMPACT: {
         const size_t lds = 4 * kWaveLds;
 #define CALL(D, T)                                                                                      \
@@ -338,6 +525,43 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     } while (0)
         PIGS_DISPATCH(P, CALL);
 #undef CALL
+        break;
+    }
+    case K1_FAST_LDS:
+    case K1_FAST_LDS_PREFETCH: {
+        const size_t lds = tab_bytes + 16 * kWaveLds;
+        const bool pf = variant == K1_FAST_LDS_PREFETCH;
+#define CALL(D, T)                                                                                      \
+    do {                                                                                                \
+        if (pf) {                                                                                       \
+            e = set_lds(k_delta_action_v2<D, T, true, false, 1024, true, true>, lds);                   \
+            if (e == hipSuccess)                                                                        \
+                hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024, true, true>), dim3(k1_grid(n_items, 16, 256)), \
+                                   dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
+        } else {                                                                                        \
+            e = set_lds(k_delta_action_v2<D, T, true, false, 1024, false, true>, lds);                  \
+            if (e == hipSuccess)                                                                        \
+                hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024, false, true>), dim3(k1_grid(n_items, 16, 256)), \
+                                   dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
+        }                                                                                               \
+    } while (0)
+        PIGS_DISPATCH(P, CALL);
+#undef CALL
+        break;
+    }
+    case K1_PIPE: {
+        const size_t lds = tab_bytes + 16 * kWaveLds;
+        int blocks = (n_items + 15) / 16;
+        if (blocks > k1_pipe_blocks()) blocks = k1_pipe_blocks();
+#define CALLP(D)                                                                                        \
+    do {                                                                                                \
+        e = set_lds(k_delta_action_pipe<D>, lds);                                                       \
+        if (e == hipSuccess)                                                                            \
+            hipLaunchKernelGGL((k_delta_action_pipe<D>), dim3(blocks), dim3(1024), lds, st, P, paths,   \
+                               VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
+    } while (0)
+        if (P.dim == 1) CALLP(1); else if (P.dim == 2) CALLP(2); else CALLP(3);
+#undef CALLP
         break;
     }
     case K1_V2_LDS_COMPACT: {

@@ -32,6 +32,36 @@ __device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, con
                                                 double r2, const double (&d)[DIM], Acc<DIM, CLS> &A,
                                                 bool pot_on = true)
 {
+    if constexpr (is_fast_tab<VTab>::value) {
+        // short arithmetic (pigs_device.h): cells are never clamped here -- PBC only, so r <= rcut keeps
+        // i0+2 <= Nmax+1; only i0-1 needs the lower clamp (r < dr, where the table head is NaN anyway, Q4)
+        const FCell C = fcell_setup(r2, P);
+        const double *V = VT.p + C.i0;
+        const double F0 = V[0], F1 = V[1];
+        if (CLS == CLS_ODD) {
+            const double Fm = VT.p[max(C.i0 - 1, 0)], Fp = V[2];
+            const double v  = __builtin_fma(C.f, F1, C.omf * F0);
+            const double Fb = __builtin_fma(C.f, F0, C.omf * Fm);
+            const double Fa = __builtin_fma(C.f, Fp, C.omf * F1);
+            const double s  = ((Fa - Fb) * P.hrdr) * C.rinv;       // (dV/dr)/r
+            if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                if (IS_OLD) A.fO[k] = __builtin_fma(s, d[k], A.fO[k]); else A.fN[k] = __builtin_fma(s, d[k], A.fN[k]);
+            }
+        } else {
+            if (pot_on) {
+                const double v = __builtin_fma(C.f, F1, C.omf * F0);
+                if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
+            }
+            if (CLS == CLS_END) {
+                const double *U = WF + C.i0;
+                const double u = __builtin_fma(C.f, U[1], C.omf * U[0]);
+                if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
+            }
+        }
+        return;
+    }
     double r, rinv;
     sqrt_rinv(r2, r, rinv);
     const FLerp L = flerp_setup(r, P);
@@ -134,6 +164,7 @@ __device__ __forceinline__ void partner_accumulate_at(const DevParams &P, VTab V
     }
     double r2n, r2o;
     if (TRAP) { r2o = plain_r2<DIM>(dold); r2n = plain_r2<DIM>(dnew); }
+    else if constexpr (is_fast_tab<VTab>::value) { r2o = min_image_rn<DIM>(dold, P); r2n = min_image_rn<DIM>(dnew, P); }
     else      { r2o = min_image_fast<DIM>(dold, P); r2n = min_image_fast<DIM>(dnew, P); }
     if (TRAP || r2n <= P.rcut2)                                       // :2723 (Q5) / :2771
         pair_accumulate<DIM, CLS, false>(P, VT, WF, r2n, dnew, A);

@@ -17,7 +17,12 @@ enum K1Variant {
     K1_V2_LDS = 3,          // + VTable in LDS
     K1_V2_COMPACT = 4,      // + in-cutoff compaction (global table)
     K1_V2_LDS_COMPACT = 5,  // + both
-    K1_V2_PREFETCH = 6      // v2 with all partner loads of an item issued up front (Np <= 256)
+    K1_V2_PREFETCH = 6,     // v2 with all partner loads of an item issued up front (Np <= 256)
+    K1_FAST = 7,            // v2 with the short arithmetic (~1 ulp per term instead of the reference's rounding; PBC)
+    K1_FAST_PREFETCH = 8,   // + prefetch
+    K1_FAST_LDS = 9,        // fast with the VTable in LDS (one 1024-thread workgroup per CU)
+    K1_FAST_LDS_PREFETCH = 10,
+    K1_PIPE = 11            // persistent: LDS table + next item's loads in flight during the current item (Np <= 256)
 };
 
 hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,
