@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -156,6 +157,10 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     if (!c) return fail(PIGS_ERR_ARG, "out of host memory");
     c->hp = *p;
     c->device = device_id;
+    if (const char *ev = getenv("PIGS_K1_VARIANT")) {           // test / tuning hook: same as pigs_set_tuning("k1_variant")
+        const int v = atoi(ev);
+        if (v >= K1_AUTO && v <= K1_PIPE) c->k1_variant = v;
+    }
     c->n_walkers = n_walkers;
     DevParams &P = c->P;
     memset(&P, 0, sizeof P);

@@ -341,23 +341,32 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
     const int wid   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t sl = slice_doubles(DIM, P.NpPad);
 
+    // Items blockIdx.x + k*gridDim.x belong to this workgroup (consecutive items -- one walker's beads, odd and
+    // even ones costing 2:1 -- spread over all CUs); its 16 waves take them from an LDS counter as they
+    // become free, so no wave idles behind a neighbour that drew the expensive items.
+    const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int k = wid;
+    ItemRec<DIM> cur;
+    // the first item's slice is requested before the table is staged: the two latencies overlap
+    if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
+
     double *tab = reinterpret_cast<double *>(smem);
     const int nt = P.Nmax + 2;
-    for (int t = threadIdx.x; t < nt; t += 1024) tab[t] = VTg[t];
+    {
+        // 16-byte copies (hipMalloc'ed table, LDS base: both 16-byte aligned)
+        const double2 *src = reinterpret_cast<const double2 *>(VTg);
+        double2 *dst = reinterpret_cast<double2 *>(tab);
+        for (int t = threadIdx.x; t < nt / 2; t += 1024) dst[t] = src[t];
+        if ((nt & 1) && threadIdx.x == 0) tab[nt - 1] = VTg[nt - 1];
+    }
     if (threadIdx.x == 0) next_local = 16;
     const size_t off = ((size_t)nt * sizeof(double) + 15) & ~(size_t)15;
     double *red = reinterpret_cast<double *>(smem + off + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
     const FastTab VT{tab};
 
-    // Items blockIdx.x + k*gridDim.x belong to this workgroup (consecutive items -- one walker's beads, odd and
-    // even ones costing 2:1 -- spread over all CUs); its 16 waves take them from an LDS counter as they
-    // become free, so no wave idles behind a neighbour that drew the expensive items.
-    const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    for (int k = wid; k < n_local;) {
+    while (k < n_local) {
         const int it = (int)blockIdx.x + k * (int)gridDim.x;
-        ItemRec<DIM> cur;
-        pipe_fetch<DIM>(P, paths, it, walker, ipv, ibv, xnew, xold, lane, sl, cur);
         int kn = 0;
         if (lane == 0) kn = atomicAdd(&next_local, 1);
         k = __builtin_amdgcn_readfirstlane(kn);
@@ -365,13 +374,14 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
         double *q = parts ? parts + (size_t)it * 3 : nullptr;
         if (!cur.ok) {
             if (lane == 0) *o = __builtin_nan("");
-            continue;
+        } else {
+            const bool odd  = (cur.b & 1) != 0;
+            const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
+            if (odd)       pipe_item<DIM, CLS_ODD>(P, VT, WF, cur, lane, red, o, q);
+            else if (endb) pipe_item<DIM, CLS_END>(P, VT, WF, cur, lane, red, o, q);
+            else           pipe_item<DIM, CLS_EVEN>(P, VT, WF, cur, lane, red, o, q);
         }
-        const bool odd  = (cur.b & 1) != 0;
-        const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
-        if (odd)       pipe_item<DIM, CLS_ODD>(P, VT, WF, cur, lane, red, o, q);
-        else if (endb) pipe_item<DIM, CLS_END>(P, VT, WF, cur, lane, red, o, q);
-        else           pipe_item<DIM, CLS_EVEN>(P, VT, WF, cur, lane, red, o, q);
+        if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
     }
 }
 
@@ -451,7 +461,13 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     const size_t tab_bytes  = (((size_t)(P.Nmax + 2) * sizeof(double)) + 15) & ~(size_t)15;
     const bool can_compact  = !P.trap && P.Np <= 256;          // 8 code slots per lane
     const bool can_ldstab   = tab_bytes + 16 * kWaveLds <= 160 * 1024;
-    if (variant == K1_AUTO) variant = K1_V2;
+    if (variant == K1_AUTO) {
+        // short arithmetic wherever there is a cutoff; the persistent LDS-table kernel once a launch has
+        // enough items to fill its 16 waves per CU several times over, the plain grid below that
+        if (P.trap) variant = K1_V2;
+        else if (P.Np <= 256 && can_ldstab && n_items >= 8 * k1_pipe_blocks()) variant = K1_PIPE;
+        else variant = P.Np <= 256 ? K1_FAST_PREFETCH : K1_FAST;
+    }
     if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
     if ((variant == K1_V2_LDS || variant == K1_V2_LDS_COMPACT) && !can_ldstab) variant = K1_V2;
     if (variant == K1_V2_PREFETCH && P.Np > 256) variant = K1_V2;

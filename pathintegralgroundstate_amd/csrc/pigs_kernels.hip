@@ -21,8 +21,8 @@ namespace pigs {
 // reference's partner order, and no antisymmetric scatter / atomics are needed; each pair is
 // visited from both sides, V counts half from each side (multiplying by 0.5 is exact), f_ji = -f_ij
 // exactly (the wrap is odd-symmetric).  Slices that need V only (even beads): each pair once,
-// thread i taking the next floor(Np/2) partners around the ring.  sqrt and the quotients use the
-// exact few-instruction forms of pigs_device.h (same bits as `sqrt` and `/`).
+// thread i taking the next floor(Np/2) partners around the ring.  Periodic systems use the short
+// arithmetic of pigs_device.h (~1 ulp per term, same cutoff decisions); the trap keeps the plain forms.
 // Optional spring term of ThermEnergy between slice ib and ib+1 (sample_mod.f90:359-380).
 // out[3*slot+0..2] = Pot, F2 (0 if !want_f2), spring sum.
 // =====================================================================================
@@ -85,15 +85,18 @@ __global__ __launch_bounds__(256) void k_slice_energy(
                 double d[DIM];
 #pragma unroll
                 for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
-                const double r2 = min_image_fast<DIM>(d, P);
+                const double r2 = min_image_rn<DIM>(d, P);
                 if (r2 <= P.rcut2) {                              // :98
-                    double r, rinv, v, dv;
-                    sqrt_rinv(r2, r, rinv);                       // exact sqrt and quotients (pigs_device.h)
-                    const FLerp L = flerp_setup(r, P);
-                    finterp01(VT, L, P, v, dv);
-                    poti = poti + v;
+                    // short arithmetic (pigs_device.h): ~1 ulp per term, cutoff decision unchanged
+                    const FCell C = fcell_setup(r2, P);
+                    const double *V = VT + C.i0;
+                    const double Fm = VT[max(C.i0 - 1, 0)], F0 = V[0], F1 = V[1], Fp = V[2];
+                    poti = poti + __builtin_fma(C.f, F1, C.omf * F0);
+                    const double Fb = __builtin_fma(C.f, F0, C.omf * Fm);
+                    const double Fa = __builtin_fma(C.f, Fp, C.omf * F1);
+                    const double sc = ((Fa - Fb) * P.hrdr) * C.rinv;
 #pragma unroll
-                    for (int k = 0; k < DIM; ++k) F[k] = F[k] + div_by(dv * d[k], r, rinv);
+                    for (int k = 0; k < DIM; ++k) F[k] = __builtin_fma(sc, d[k], F[k]);
                 }
             }
             poti = 0.5 * poti;
@@ -107,10 +110,11 @@ __global__ __launch_bounds__(256) void k_slice_energy(
                 double d[DIM];
 #pragma unroll
                 for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
-                const double r2 = min_image_fast<DIM>(d, P);
+                const double r2 = min_image_rn<DIM>(d, P);
                 if (r2 <= P.rcut2) {
-                    const FLerp L = flerp_setup(sqrt_exact(r2), P);
-                    poti = poti + finterp0(VT, L, P);
+                    const FCell C = fcell_setup(r2, P);
+                    const double *V = VT + C.i0;
+                    poti = poti + __builtin_fma(C.f, V[1], C.omf * V[0]);
                 }
             }
         }

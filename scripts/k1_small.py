@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""K1 launch time vs number of items (prologue / tail of the persistent kernel against the plain grid)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import make_workload  # noqa: E402
+from pathintegralgroundstate_amd import SystemConfig, api  # noqa: E402
+
+
+def main():
+    cfg = SystemConfig(dim=3, Np=256, Nb=80)
+    VT, WF = api.build_tables(cfg)
+    W = 128
+    Paths, sets = make_workload(cfg, W, 1, 1982)
+    dev = torch.device("cuda", 0)
+    ctx = api.PigsContext(cfg, VT, WF, n_walkers=W)
+    ctx.upload_all(Paths)
+    d = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in sets[0])
+    n_all = len(sets[0][0])
+    out = torch.zeros(n_all, dtype=torch.float64, device=dev)
+    ks = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    for v in [int(x) for x in os.environ.get("VARIANTS", "2,8,11").split(",")]:
+        ctx.set_tuning("k1_variant", v)
+        for n in (16, 256, 1024, 4096, 8192, 12288, 16384, n_all):
+            w, ip, ib, xn, xo = d
+            for _ in range(5):
+                ctx.delta_action_batch_dev(n, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(), out.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ks)
+            for _ in range(100):
+                ctx.delta_action_batch_dev(n, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(), out.data_ptr())
+            e1.record(ks)
+            ctx.sync()
+            print(f"variant {v:2d}  n_items {n:6d}: {e0.elapsed_time(e1) * 10:8.2f} us per launch", flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,7 +115,7 @@ def test_short_division_and_sqrt_are_exact(gpu_lib):
     assert n == 2048 * 256 * 512 and bad == [0, 0, 0, 0], bad
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "pbc2d_n16", "trap3d_n8"])
 def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
     d = load_golden(name)
@@ -135,6 +135,47 @@ def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
     u = np.random.default_rng(1).uniform(size=n)
     with np.errstate(over="ignore", invalid="ignore"):
         assert np.array_equal(np.exp(-dS) >= u, np.exp(-ref) >= u)
+
+
+@pytest.mark.parametrize("Np,Nb,W,n", [(256, 80, 6, 30000), (64, 40, 3, 6000)])
+def test_short_arithmetic_vs_exact_forms(gpu_lib, oracle, Np, Nb, W, n):
+    """The library's default Delta-S arithmetic for periodic systems (variants 7-11: rint minimum image, one
+    Newton step after v_rsq_f64, interpolation in the normalised cell coordinate) against the variant that keeps
+    the reference's rounding of every term (2): each part -- DeltaPot, DeltaF2, DeltaLogPsi -- agrees to 2e-13 of
+    the sum of its terms' magnitudes (the tolerance the oracle tests use), the Metropolis decision on a common
+    uniform is the same, and the cutoff membership is identical (r^2 keeps the reference's rounding sequence)."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(dim=3, Np=Np, Nb=Nb)
+    cfg = SystemConfig(dim=3, Np=Np, Nb=Nb)
+    VT, WF = oracle.tables(S)
+    Paths = _worldlines(oracle, S, W, 5, 0.12)
+    rng = np.random.default_rng(11)
+    w, ip, ib, xnew, xold = _random_batch(rng, S, Paths, n, 0.1)
+    res = {}
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        for v in (2, 7, 8, 9, 10, 11, 0):
+            ctx.set_tuning("k1_variant", v)
+            res[v] = (ctx.delta_action_batch(w, ip, ib, xnew, xold), ctx.delta_action_parts(w, ip, ib, xnew, xold))
+    sv = np.zeros(n); sf = np.zeros(n); su = np.zeros(n)
+    for k in range(W):
+        m = w == k
+        sv[m], sf[m], su[m] = term_scales(S, VT, WF, Paths[k], ip[m], ib[m], xnew[m], xold[m])
+    tol = delta_s_tolerance(S, sv, sf, su)
+    ex, exp_ = res[2]
+    fin = np.isfinite(ex)
+    u = rng.uniform(size=n)
+    for v in (7, 8, 9, 10, 11, 0):
+        dS, parts = res[v]
+        assert np.array_equal(np.isnan(dS), np.isnan(ex)), v
+        assert np.all(np.abs(dS - ex)[fin] <= tol[fin]), (v, np.max((np.abs(dS - ex) / tol)[fin]))
+        assert np.all(np.abs(parts[:, 0] - exp_[:, 0])[fin] <= 2e-13 * sv[fin] + 1e-300), v
+        assert np.all(np.abs(parts[:, 2] - exp_[:, 2])[fin] <= 2e-13 * su[fin] + 1e-300), v
+        with np.errstate(over="ignore", invalid="ignore"):
+            assert np.array_equal(np.exp(-dS) >= u, np.exp(-ex) >= u), v
+    # all short-arithmetic variants evaluate the same expressions: their results differ by summation order only
+    assert np.all(np.abs(res[7][0] - res[11][0])[fin] <= tol[fin])
 
 
 def _random_batch(rng, S, Paths, n, sigma):
