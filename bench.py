@@ -37,6 +37,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# K1 kernel behind each k1_variant on the bench workload (0 = the library's choice: periodic system, Np <= 256,
+# a launch of >= 8 items per CU -> the persistent LDS-table kernel with the short arithmetic)
+K1_KERNELS = {0: "pigs::k_delta_action_pipe<3>", 11: "pigs::k_delta_action_pipe<3>",
+              2: "pigs::k_delta_action_v2<3,false,false,false,256,false,false>"}
+
+
 def make_workload(cfg, W, nsets, seed):
     """Seeded synthetic worldlines + `nsets` full-chain proposal stages."""
     rng = np.random.default_rng(seed)
@@ -207,7 +213,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic.json")) as f:
             tj = json.load(f)
-        if tj.get("algorithmic_bytes_per_launch") == alg_bytes:
+        if tj.get("algorithmic_bytes_per_launch") == alg_bytes and tj.get("kernel") == K1_KERNELS.get(args.variant):
             traffic = tj["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -296,7 +302,8 @@ def main():
                        "stages_per_sweep_equiv": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pigs::k_delta_action_v2<3,false,false,false,256>", "kernel_ms": kern_ms,
+                         "kernel": K1_KERNELS.get(args.variant, "pigs::k_delta_action_v2<...> (variant %d)" % args.variant),
+                         "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),
