@@ -159,7 +159,7 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     c->device = device_id;
     if (const char *ev = getenv("PIGS_K1_VARIANT")) {           // test / tuning hook: same as pigs_set_tuning("k1_variant")
         const int v = atoi(ev);
-        if (v >= K1_AUTO && v <= K1_PIPE) c->k1_variant = v;
+        if (v >= K1_AUTO && v <= K1_PIPE2) c->k1_variant = v;
     }
     c->n_walkers = n_walkers;
     DevParams &P = c->P;
@@ -242,7 +242,7 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
 {
     if (!c || !key) return fail(PIGS_ERR_ARG, "null pointer");
     if (!strcmp(key, "k1_variant")) {
-        if (value < K1_AUTO || value > K1_PIPE) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
+        if (value < K1_AUTO || value > K1_PIPE2) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
         c->k1_variant = value;
         return PIGS_OK;
     }

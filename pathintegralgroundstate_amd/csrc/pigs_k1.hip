@@ -270,38 +270,81 @@ __device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__r
     }
 }
 
-// one distance, branch-free: lanes outside the cutoff (or without a partner) evaluate the cell of rcut and
-// enter the sums with weight 0 through the accumulating fma (fma(v, 1, acc) rounds like acc + v), so the new
-// and the old distance are independent straight-line chains the scheduler interleaves
+// LDS image of the VTable used by the pipe kernels: [VT(0)] VT(0) .. VT(Nmax+1) [0 0 0 0]
+//   * the leading copy of VT(0) stands for the reference's clamp max(ix-2,0) at r < dr;
+//   * the trailing zeros are the "zero cell": a lane whose distance is outside the cutoff (or that has no
+//     partner) looks up cell zc = Nmax+3 and so contributes exactly 0 to every sum -- no weights, no selects
+//     on the results.
+struct PipeTab {
+    const double *p;      // -> VT(0) inside LDS
+    int zc;
+};
+
+__device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt + 6) * sizeof(double) + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ PipeTab pipe_stage_table(unsigned char *smem, const double *__restrict__ VTg, int nt)
+{
+    double *base = reinterpret_cast<double *>(smem);          // base[1] = leading copy, base[2..] = table
+    double *tab  = base + 2;
+    {
+        // 16-byte copies (hipMalloc'ed table, tab = smem + 16: both 16-byte aligned)
+        const double2 *src = reinterpret_cast<const double2 *>(VTg);
+        double2 *dst = reinterpret_cast<double2 *>(tab);
+        for (int t = threadIdx.x; t < nt / 2; t += blockDim.x) dst[t] = src[t];
+        if (threadIdx.x == 0) {
+            if (nt & 1) tab[nt - 1] = VTg[nt - 1];
+            base[0] = 0.0; base[1] = VTg[0];
+            tab[nt] = 0.0; tab[nt + 1] = 0.0; tab[nt + 2] = 0.0; tab[nt + 3] = 0.0;
+        }
+    }
+    return PipeTab{tab, nt + 1};
+}
+
+// one distance, branch-free and weight-free (see PipeTab).  r2 must be finite and > 0 on every lane (the caller
+// floors it at 1e-300: a lane measuring the moved particle against its own row has r2 = 0).
+//   r   = sqrt(r2) from v_rsq_f64 (2^-24) + one coupled Newton step + one residual correction (< 1 ulp)
+//   t   = r/dr,  i0 = int(t) = ix-1 of the reference,  f = fract(t)
+//   V   = F0 + f (F1-F0);   dV/dr * dr = (F1-Fm) + f ((Fp-F1) - (F0-Fm))   [= Fafter - Fbefore of interpolate.f90]
+//   force term (dV/dr)/r * x_k with 1/r = 2h from the same Newton step
 template <int DIM, int CLS, bool IS_OLD>
-__device__ __forceinline__ void pipe_pair(const DevParams &P, FastTab VT, const double *__restrict__ WF,
+__device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
                                           double r2, bool in, const double (&d)[DIM], Acc<DIM, CLS> &A)
 {
-    const double wgt = in ? 1.0 : 0.0;
-    const FCell C = fcell_setup(in ? r2 : P.rcut2, P);
-    const double *V = VT.p + C.i0;
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    double g = r2 * y0;
+    double h = 0.5 * y0;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    const double d0 = __builtin_fma(-g, g, r2);
+    g = __builtin_fma(d0, h, g);
+    const double t  = g * P.rdr;
+    const int    it = (int)t;
+    const int    i0 = in ? it : VT.zc;
+    const double f  = __builtin_amdgcn_fract(t);
+    const double *V = VT.p + i0;
     const double F0 = V[0], F1 = V[1];
-    const double v = __builtin_fma(C.f, F1, C.omf * F0);
-    if (IS_OLD) A.potO = __builtin_fma(v, wgt, A.potO); else A.potN = __builtin_fma(v, wgt, A.potN);
+    const double v  = __builtin_fma(f, F1 - F0, F0);
+    if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
     if (CLS == CLS_ODD) {
-        const double Fm = VT.p[max(C.i0 - 1, 0)], Fp = V[2];
-        const double Fb = __builtin_fma(C.f, F0, C.omf * Fm);
-        const double Fa = __builtin_fma(C.f, Fp, C.omf * F1);
-        const double s  = (((Fa - Fb) * P.hrdr) * C.rinv) * wgt;       // (dV/dr)/r
+        const double Fm = V[-1], Fp = V[2];
+        const double D  = __builtin_fma(f, (Fp - F1) - (F0 - Fm), F1 - Fm);
+        const double s  = D * (h * P.rdr);                                // ((Fafter-Fbefore)*0.5/dr) * (2h)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
             if (IS_OLD) A.fO[k] = __builtin_fma(s, d[k], A.fO[k]); else A.fN[k] = __builtin_fma(s, d[k], A.fN[k]);
         }
     }
-    if (CLS == CLS_END) {
-        const double *U = WF + C.i0;
-        const double u = __builtin_fma(C.f, U[1], C.omf * U[0]);
-        if (IS_OLD) A.psiO = __builtin_fma(u, wgt, A.psiO); else A.psiN = __builtin_fma(u, wgt, A.psiN);
+    if (CLS == CLS_END) {                                                 // LogWF stays in global memory (2 of 161 beads)
+        const double *U = WF + (in ? it : 0);
+        const double u0 = U[0], u1 = U[1];
+        const double u  = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;    // (1-f)*(-Inf) keeps the -Inf head (Q4)
+        if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
     }
 }
 
 template <int DIM, int CLS>
-__device__ __forceinline__ void pipe_item(const DevParams &P, FastTab VT, const double *__restrict__ WF,
+__device__ __forceinline__ void pipe_item(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
                                           const ItemRec<DIM> &R, int lane, double *red, double *out, double *parts)
 {
     Acc<DIM, CLS> A;
@@ -320,8 +363,8 @@ __device__ __forceinline__ void pipe_item(const DevParams &P, FastTab VT, const 
         }
         const double r2o = min_image_rn<DIM>(dold, P);
         const double r2n = min_image_rn<DIM>(dn, P);
-        pipe_pair<DIM, CLS, false>(P, VT, WF, r2n, valid && r2n <= P.rcut2, dn, A);
-        pipe_pair<DIM, CLS, true>(P, VT, WF, r2o, valid && r2o <= P.rcut2, dold, A);
+        pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
+        pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
         __builtin_amdgcn_sched_barrier(0);                            // two chains in flight, not eight (VGPRs)
     }
     finish_item<DIM, CLS>(P, lane, R.b, A, red, out, parts);
@@ -350,20 +393,11 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
     // the first item's slice is requested before the table is staged: the two latencies overlap
     if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
 
-    double *tab = reinterpret_cast<double *>(smem);
     const int nt = P.Nmax + 2;
-    {
-        // 16-byte copies (hipMalloc'ed table, LDS base: both 16-byte aligned)
-        const double2 *src = reinterpret_cast<const double2 *>(VTg);
-        double2 *dst = reinterpret_cast<double2 *>(tab);
-        for (int t = threadIdx.x; t < nt / 2; t += 1024) dst[t] = src[t];
-        if ((nt & 1) && threadIdx.x == 0) tab[nt - 1] = VTg[nt - 1];
-    }
+    const PipeTab VT = pipe_stage_table(smem, VTg, nt);
     if (threadIdx.x == 0) next_local = 16;
-    const size_t off = ((size_t)nt * sizeof(double) + 15) & ~(size_t)15;
-    double *red = reinterpret_cast<double *>(smem + off + (size_t)wid * kWaveLds);
+    double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
-    const FastTab VT{tab};
 
     while (k < n_local) {
         const int it = (int)blockIdx.x + k * (int)gridDim.x;
@@ -382,6 +416,215 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
             else           pipe_item<DIM, CLS_EVEN>(P, VT, WF, cur, lane, red, o, q);
         }
         if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
+    }
+}
+
+// =====================================================================================
+// K1 "pipe2": the pipe kernel with the per-item stall taken out of the critical path.  In `pipe` a wave
+// starts every item with a dependent chain -- scalar loads of the item record, then the slice loads whose
+// address they give, ~3 us -- and with 4 waves per SIMD nothing can cover all of it (78 % VALU occupancy in
+// steady state).  Here (a) the record of the item AFTER the next one is requested with vector loads
+// (lanes 0..2: walker/ip/ib, lanes 0..2*DIM-1: xnew,xold; vmcnt is in order, unlike scalar loads it does not
+// force an lgkmcnt drain at the next LDS gather) and decoded one item later with v_readlane, (b) the
+// partner coordinates run two passes ahead: pass m+2 of this item, then passes 0/1 of the next item, are
+// requested before pass m is evaluated, in the same 4 x DIM registers.
+// =====================================================================================
+template <int DIM>
+struct ItemMeta {                                   // wave-uniform (SGPRs)
+    int    p, b, ok;
+    const double *S;
+    double xn[DIM], xo[DIM];
+};
+
+struct ItemRaw {
+    int    i;      // lane 0 walker, 1 ip, 2 ib
+    double x;      // lanes 0..DIM-1 xnew, DIM..2*DIM-1 xold
+};
+
+template <int DIM>
+__device__ __forceinline__ ItemRaw pipe2_request(int it, const int32_t *__restrict__ walker,
+                                                 const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+                                                 const double *__restrict__ xnew, const double *__restrict__ xold, int lane)
+{
+    ItemRaw r;
+    const int32_t *ai = lane == 0 ? walker : (lane == 1 ? ipv : ibv);
+    r.i = ai[it];
+    const int k = lane < DIM ? lane : (lane < 2 * DIM ? lane - DIM : 0);
+    const double *ax = lane < DIM ? xnew : xold;
+    r.x = ax[(size_t)it * DIM + k];
+    return r;
+}
+
+__device__ __forceinline__ double bcast_lane(double v, int lane_id)
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane_id);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane_id);
+    return u.d;
+}
+
+template <int DIM>
+__device__ __forceinline__ void pipe2_decode(const DevParams &P, const double *__restrict__ paths, const ItemRaw &r,
+                                             size_t sl, ItemMeta<DIM> &R)
+{
+    const int w = __builtin_amdgcn_readlane(r.i, 0);
+    R.p = __builtin_amdgcn_readlane(r.i, 1) - 1;
+    R.b = __builtin_amdgcn_readlane(r.i, 2);
+    R.ok = (unsigned)w < (unsigned)P.nW && (unsigned)R.p < (unsigned)P.Np && (unsigned)R.b < (unsigned)P.M;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        R.xn[k] = bcast_lane(r.x, k);
+        R.xo[k] = bcast_lane(r.x, DIM + k);
+    }
+    R.S = paths + (R.ok ? ((size_t)w * P.M + R.b) * sl : 0);
+}
+
+// only the slice address of a record (what the coordinate lookahead needs mid-item; the full decode waits
+// for the item's own turn so that two decoded records never compete for SGPRs)
+template <int DIM>
+__device__ __forceinline__ const double *pipe2_slice(const DevParams &P, const double *__restrict__ paths, const ItemRaw &r, size_t sl)
+{
+    const int w = __builtin_amdgcn_readlane(r.i, 0);
+    const int p = __builtin_amdgcn_readlane(r.i, 1) - 1;
+    const int b = __builtin_amdgcn_readlane(r.i, 2);
+    const bool ok = (unsigned)w < (unsigned)P.nW && (unsigned)p < (unsigned)P.Np && (unsigned)b < (unsigned)P.M;
+    return paths + (ok ? ((size_t)w * P.M + b) * sl : 0);
+}
+
+template <int DIM>
+__device__ __forceinline__ void pipe2_load(const DevParams &P, const double *__restrict__ S, int m, int lane,
+                                           double (&rj)[DIM])
+{
+    const int j  = m * kWave + lane;
+    const int jj = j < P.Np ? j : 0;                                  // in-bounds dummy for idle lanes
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + jj];
+}
+
+template <int DIM, int CLS, int M>
+__device__ __forceinline__ void pipe2_pass(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                           const ItemMeta<DIM> &R, const double (&rjm)[DIM], int lane, Acc<DIM, CLS> &A)
+{
+    const int j = M * kWave + lane;
+    const bool valid = j < P.Np && j != R.p;
+    double dn[DIM], dold[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        double rj = rjm[k];
+        asm volatile("; class %1 pass %2" : "+v"(rj) : "n"(CLS), "n"(M));     // see pipe_item
+        dn[k] = R.xn[k] - rj; dold[k] = R.xo[k] - rj;
+    }
+    const double r2o = min_image_rn<DIM>(dold, P);
+    const double r2n = min_image_rn<DIM>(dn, P);
+    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
+    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// per-wave pipeline state that crosses items
+template <int DIM>
+struct PipeState {
+    ItemRaw raw_next;         // the next item's record (requested one item ago; decoded when its turn comes)
+    ItemRaw raw_nn;           // record of the item after it (requested mid-item)
+    int k_nn;                 // queue index of that item
+    double a0[DIM], a1[DIM];  // passes 0/1: of the current item on entry, of the next item on exit
+};
+
+template <int DIM, int CLS>
+__device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                           const double *__restrict__ paths, size_t sl, int n_local, int *queue,
+                                           const int32_t *__restrict__ walker, const int32_t *__restrict__ ipv,
+                                           const int32_t *__restrict__ ibv, const double *__restrict__ xnew,
+                                           const double *__restrict__ xold,
+                                           const ItemMeta<DIM> &R, PipeState<DIM> &st, int lane, double *red,
+                                           double *out, double *parts)
+{
+    Acc<DIM, CLS> A;
+    double b0[DIM], b1[DIM];
+    pipe2_load<DIM>(P, R.S, 2, lane, b0);
+    pipe2_pass<DIM, CLS, 0>(P, VT, WF, R, st.a0, lane, A);
+    pipe2_load<DIM>(P, R.S, 3, lane, b1);
+    pipe2_pass<DIM, CLS, 1>(P, VT, WF, R, st.a1, lane, A);
+    // the next item's record arrived an item ago; the one after it is drawn from the queue and requested now
+    const double *Snext = pipe2_slice<DIM>(P, paths, st.raw_next, sl);
+    {
+        int kn = 0;
+        if (lane == 0) kn = atomicAdd(queue, 1);
+        kn = __builtin_amdgcn_readfirstlane(kn);
+        st.k_nn = kn;
+        const int kq = kn < n_local ? kn : 0;                         // past the end: any valid record
+        st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + kq * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane);
+    }
+    pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
+    pipe2_pass<DIM, CLS, 2>(P, VT, WF, R, b0, lane, A);
+    pipe2_load<DIM>(P, Snext, 1, lane, st.a1);
+    pipe2_pass<DIM, CLS, 3>(P, VT, WF, R, b1, lane, A);
+    finish_item<DIM, CLS>(P, lane, R.b, A, red, out, parts);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(1024) void k_delta_action_pipe2(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int next_local;                                  // this workgroup's item queue
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+    const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    // first two items of this wave: static (k = wid, wid + 16); the queue starts behind them
+    int k_cur = wid, k_nx = wid + 16;
+    ItemMeta<DIM> cur;
+    PipeState<DIM> st;
+    {
+        const ItemRaw r0 = pipe2_request<DIM>((int)blockIdx.x + (k_cur < n_local ? k_cur : 0) * (int)gridDim.x,
+                                              walker, ipv, ibv, xnew, xold, lane);
+        st.raw_next = pipe2_request<DIM>((int)blockIdx.x + (k_nx < n_local ? k_nx : 0) * (int)gridDim.x,
+                                         walker, ipv, ibv, xnew, xold, lane);
+        pipe2_decode<DIM>(P, paths, r0, sl, cur);
+        pipe2_load<DIM>(P, cur.S, 0, lane, st.a0);
+        pipe2_load<DIM>(P, cur.S, 1, lane, st.a1);
+    }
+
+    const int nt = P.Nmax + 2;
+    const PipeTab VT = pipe_stage_table(smem, VTg, nt);
+    if (threadIdx.x == 0) next_local = 32;
+    double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
+    __syncthreads();                                            // the only workgroup barrier
+
+    while (k_cur < n_local) {                                   // wave-uniform
+        const int it = (int)blockIdx.x + k_cur * (int)gridDim.x;
+        double *o = out + it;
+        double *q = parts ? parts + (size_t)it * 3 : nullptr;
+        if (!cur.ok) {
+            // malformed item: NaN result; keep the pipeline moving without evaluating anything
+            if (lane == 0) *o = __builtin_nan("");
+            const double *Snext = pipe2_slice<DIM>(P, paths, st.raw_next, sl);
+            int kn = 0;
+            if (lane == 0) kn = atomicAdd(&next_local, 1);
+            kn = __builtin_amdgcn_readfirstlane(kn);
+            st.k_nn = kn;
+            st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + (kn < n_local ? kn : 0) * (int)gridDim.x,
+                                           walker, ipv, ibv, xnew, xold, lane);
+            pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
+            pipe2_load<DIM>(P, Snext, 1, lane, st.a1);
+        } else {
+            const bool odd  = (cur.b & 1) != 0;
+            const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
+            if (odd)       pipe2_item<DIM, CLS_ODD>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
+            else if (endb) pipe2_item<DIM, CLS_END>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
+            else           pipe2_item<DIM, CLS_EVEN>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
+        }
+        pipe2_decode<DIM>(P, paths, st.raw_next, sl, cur);       // arrived long ago: readlanes only
+        k_cur = k_nx;
+        k_nx = st.k_nn;
+        st.raw_next = st.raw_nn;
     }
 }
 
@@ -460,12 +703,13 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     if (n_items <= 0) return hipSuccess;
     const size_t tab_bytes  = (((size_t)(P.Nmax + 2) * sizeof(double)) + 15) & ~(size_t)15;
     const bool can_compact  = !P.trap && P.Np <= 256;          // 8 code slots per lane
-    const bool can_ldstab   = tab_bytes + 16 * kWaveLds <= 160 * 1024;
+    const size_t pipe_bytes = (((size_t)(P.Nmax + 2 + 6) * sizeof(double)) + 15) & ~(size_t)15;   // pipe_tab_bytes()
+    const bool can_ldstab   = pipe_bytes + 16 * kWaveLds <= 160 * 1024;
     if (variant == K1_AUTO) {
         // short arithmetic wherever there is a cutoff; the persistent LDS-table kernel once a launch has
         // enough items to fill its 16 waves per CU several times over, the plain grid below that
         if (P.trap) variant = K1_V2;
-        else if (P.Np <= 256 && can_ldstab && n_items >= 8 * k1_pipe_blocks()) variant = K1_PIPE;
+        else if (P.Np <= 256 && can_ldstab && n_items >= 8 * k1_pipe_blocks()) variant = K1_PIPE2;
         else variant = P.Np <= 256 ? K1_FAST_PREFETCH : K1_FAST;
     }
     if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
@@ -473,7 +717,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     if (variant == K1_V2_PREFETCH && P.Np > 256) variant = K1_V2;
     if (variant == K1_FAST_PREFETCH && P.Np > 256) variant = K1_FAST;
     if ((variant == K1_FAST_LDS || variant == K1_FAST_LDS_PREFETCH) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
-    if (variant == K1_PIPE && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
+    if ((variant == K1_PIPE || variant == K1_PIPE2) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
     if (variant >= K1_FAST && P.trap) variant = K1_V2;   // no cutoff in the trap: exact path
     hipError_t e = hipSuccess;
     switch (variant) {
@@ -566,7 +810,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
         break;
     }
     case K1_PIPE: {
-        const size_t lds = tab_bytes + 16 * kWaveLds;
+        const size_t lds = pipe_bytes + 16 * kWaveLds;
         int blocks = (n_items + 15) / 16;
         if (blocks > k1_pipe_blocks()) blocks = k1_pipe_blocks();
 #define CALLP(D)                                                                                        \
@@ -574,6 +818,21 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
         e = set_lds(k_delta_action_pipe<D>, lds);                                                       \
         if (e == hipSuccess)                                                                            \
             hipLaunchKernelGGL((k_delta_action_pipe<D>), dim3(blocks), dim3(1024), lds, st, P, paths,   \
+                               VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
+    } while (0)
+        if (P.dim == 1) CALLP(1); else if (P.dim == 2) CALLP(2); else CALLP(3);
+#undef CALLP
+        break;
+    }
+    case K1_PIPE2: {
+        const size_t lds = pipe_bytes + 16 * kWaveLds;
+        int blocks = (n_items + 15) / 16;
+        if (blocks > k1_pipe_blocks()) blocks = k1_pipe_blocks();
+#define CALLP(D)                                                                                        \
+    do {                                                                                                \
+        e = set_lds(k_delta_action_pipe2<D>, lds);                                                      \
+        if (e == hipSuccess)                                                                            \
+            hipLaunchKernelGGL((k_delta_action_pipe2<D>), dim3(blocks), dim3(1024), lds, st, P, paths,  \
                                VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
     } while (0)
         if (P.dim == 1) CALLP(1); else if (P.dim == 2) CALLP(2); else CALLP(3);

@@ -22,7 +22,8 @@ enum K1Variant {
     K1_FAST_PREFETCH = 8,   // + prefetch
     K1_FAST_LDS = 9,        // fast with the VTable in LDS (one 1024-thread workgroup per CU)
     K1_FAST_LDS_PREFETCH = 10,
-    K1_PIPE = 11            // persistent: LDS table + next item's loads in flight during the current item (Np <= 256)
+    K1_PIPE = 11,           // persistent: LDS table, branch-free short arithmetic, per-workgroup item queue (Np <= 256)
+    K1_PIPE2 = 12           // + item records and partner coordinates requested one item / two passes ahead
 };
 
 hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from bench import make_workload  # noqa: E402
 from pathintegralgroundstate_amd import SystemConfig, api  # noqa: E402
 
-NAMES = {1: "v1 plain", 2: "v2 shortdiv", 3: "v2 +LDS table", 4: "v2 +compact", 5: "v2 +LDS+compact", 6: "v2 +prefetch", 7: "fast", 8: "fast +prefetch", 9: "fast +LDS table", 10: "fast +LDS +prefetch", 11: "pipe"}
+NAMES = {1: "v1 plain", 2: "v2 shortdiv", 3: "v2 +LDS table", 4: "v2 +compact", 5: "v2 +LDS+compact", 6: "v2 +prefetch", 7: "fast", 8: "fast +prefetch", 9: "fast +LDS table", 10: "fast +LDS +prefetch", 11: "pipe", 12: "pipe2"}
 
 
 def main():

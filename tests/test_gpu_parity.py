@@ -115,7 +115,7 @@ def test_short_division_and_sqrt_are_exact(gpu_lib):
     assert n == 2048 * 256 * 512 and bad == [0, 0, 0, 0], bad
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "pbc2d_n16", "trap3d_n8"])
 def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
     d = load_golden(name)
@@ -139,7 +139,7 @@ def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
 
 @pytest.mark.parametrize("Np,Nb,W,n", [(256, 80, 6, 30000), (64, 40, 3, 6000)])
 def test_short_arithmetic_vs_exact_forms(gpu_lib, oracle, Np, Nb, W, n):
-    """The library's default Delta-S arithmetic for periodic systems (variants 7-11: rint minimum image, one
+    """The library's default Delta-S arithmetic for periodic systems (variants 7-12: rint minimum image, one
     Newton step after v_rsq_f64, interpolation in the normalised cell coordinate) against the variant that keeps
     the reference's rounding of every term (2): each part -- DeltaPot, DeltaF2, DeltaLogPsi -- agrees to 2e-13 of
     the sum of its terms' magnitudes (the tolerance the oracle tests use), the Metropolis decision on a common
@@ -155,7 +155,7 @@ def test_short_arithmetic_vs_exact_forms(gpu_lib, oracle, Np, Nb, W, n):
     res = {}
     with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
         ctx.upload_all(Paths)
-        for v in (2, 7, 8, 9, 10, 11, 0):
+        for v in (2, 7, 8, 9, 10, 11, 12, 0):
             ctx.set_tuning("k1_variant", v)
             res[v] = (ctx.delta_action_batch(w, ip, ib, xnew, xold), ctx.delta_action_parts(w, ip, ib, xnew, xold))
     sv = np.zeros(n); sf = np.zeros(n); su = np.zeros(n)
@@ -166,7 +166,7 @@ def test_short_arithmetic_vs_exact_forms(gpu_lib, oracle, Np, Nb, W, n):
     ex, exp_ = res[2]
     fin = np.isfinite(ex)
     u = rng.uniform(size=n)
-    for v in (7, 8, 9, 10, 11, 0):
+    for v in (7, 8, 9, 10, 11, 12, 0):
         dS, parts = res[v]
         assert np.array_equal(np.isnan(dS), np.isnan(ex)), v
         assert np.all(np.abs(dS - ex)[fin] <= tol[fin]), (v, np.max((np.abs(dS - ex) / tol)[fin]))
