@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 # K1 kernel behind each k1_variant on the bench workload (0 = the library's choice: periodic system, Np <= 256,
-# a launch of >= 8 items per CU -> the persistent LDS-table kernel with the short arithmetic)
+# a launch of >= 16 items per CU -> the persistent LDS-table kernel with the short arithmetic)
 K1_KERNELS = {0: "pigs::k_delta_action_pipe2<3>", 11: "pigs::k_delta_action_pipe<3>", 12: "pigs::k_delta_action_pipe2<3>",
               2: "pigs::k_delta_action_v2<3,false,false,false,256,false,false>"}
 

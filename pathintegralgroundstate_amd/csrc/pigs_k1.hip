@@ -288,9 +288,29 @@ __device__ __forceinline__ PipeTab pipe_stage_table(unsigned char *smem, const d
     double *tab  = base + 2;
     {
         // 16-byte copies (hipMalloc'ed table, tab = smem + 16: both 16-byte aligned)
+        // all of a thread's loads are issued before its first LDS write (a plain copy loop compiles to
+        // load - wait - write per iteration: five serialized L2 round trips, 2 us)
         const double2 *src = reinterpret_cast<const double2 *>(VTg);
         double2 *dst = reinterpret_cast<double2 *>(tab);
-        for (int t = threadIdx.x; t < nt / 2; t += blockDim.x) dst[t] = src[t];
+        constexpr int U = 5;
+        const int n2 = nt / 2;
+#ifdef PIGS_EXPERIMENT_NO_STAGE
+        for (int base = 0; base < 0; base += U * (int)blockDim.x) {
+#else
+        for (int base = 0; base < n2; base += U * (int)blockDim.x) {
+#endif
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+                v[u] = src[idx < n2 ? idx : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+                if (idx < n2) dst[idx] = v[u];
+            }
+        }
         if (threadIdx.x == 0) {
             if (nt & 1) tab[nt - 1] = VTg[nt - 1];
             base[0] = 0.0; base[1] = VTg[0];
@@ -709,7 +729,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
         // short arithmetic wherever there is a cutoff; the persistent LDS-table kernel once a launch has
         // enough items to fill its 16 waves per CU several times over, the plain grid below that
         if (P.trap) variant = K1_V2;
-        else if (P.Np <= 256 && can_ldstab && n_items >= 8 * k1_pipe_blocks()) variant = K1_PIPE2;
+        else if (P.Np <= 256 && can_ldstab && n_items >= 16 * k1_pipe_blocks()) variant = K1_PIPE2;
         else variant = P.Np <= 256 ? K1_FAST_PREFETCH : K1_FAST;
     }
     if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
