@@ -87,6 +87,7 @@ struct pigs_ctx {
     int         n_walkers = 0;
     hipStream_t stream    = nullptr;
     double *d_paths = nullptr, *d_VT = nullptr, *d_WF = nullptr;
+    double *d_VTimg = nullptr;           // [0, VT(0)] VT(0..Nmax+1) [0 0 0 0]: PipeTab image for the sampler (pigs_k1_device.h)
     size_t  path_doubles = 0;        // resident doubles per walker (padded SoA)
     size_t  raw_doubles  = 0;        // dim*Np*(2Nb+1): reference layout per walker
     DevBuf<int32_t> d_walker, d_ip, d_ib, d_slotw, d_slotb;
@@ -188,6 +189,13 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
         if (hipMalloc((void **)&c->d_paths, c->path_doubles * n_walkers * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         if (hipMemcpy(c->d_VT, VTable, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         if (hipMemcpy(c->d_WF, LogWF, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        {
+            std::vector<double> img((size_t)p->Nmax + 2 + 6, 0.0);
+            img[1] = VTable[0];
+            memcpy(&img[2], VTable, tb);
+            if (hipMalloc((void **)&c->d_VTimg, img.size() * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+            if (hipMemcpy(c->d_VTimg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        }
         if (hipMemset(c->d_paths, 0, c->path_doubles * n_walkers * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
     } while (0);
     if (rc != PIGS_OK) {
@@ -218,6 +226,7 @@ int pigs_ctx_destroy(pigs_ctx *c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_VT) (void)hipFree(c->d_VT);
+    if (c->d_VTimg) (void)hipFree(c->d_VTimg);
     if (c->d_WF) (void)hipFree(c->d_WF);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -608,7 +617,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
     SweepParams sp = c->sweep;
     sp.do_cm = (istep % c->cm_freq) == 0;
-    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_WF, c->d_rng, c->d_counters,
+    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
                         c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
     return PIGS_OK;
 }

@@ -270,16 +270,6 @@ __device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__r
     }
 }
 
-// LDS image of the VTable used by the pipe kernels: [VT(0)] VT(0) .. VT(Nmax+1) [0 0 0 0]
-//   * the leading copy of VT(0) stands for the reference's clamp max(ix-2,0) at r < dr;
-//   * the trailing zeros are the "zero cell": a lane whose distance is outside the cutoff (or that has no
-//     partner) looks up cell zc = Nmax+3 and so contributes exactly 0 to every sum -- no weights, no selects
-//     on the results.
-struct PipeTab {
-    const double *p;      // -> VT(0) inside LDS
-    int zc;
-};
-
 __device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt + 6) * sizeof(double) + 15) & ~(size_t)15; }
 
 __device__ __forceinline__ PipeTab pipe_stage_table(unsigned char *smem, const double *__restrict__ VTg, int nt)
@@ -318,49 +308,6 @@ __device__ __forceinline__ PipeTab pipe_stage_table(unsigned char *smem, const d
         }
     }
     return PipeTab{tab, nt + 1};
-}
-
-// one distance, branch-free and weight-free (see PipeTab).  r2 must be finite and > 0 on every lane (the caller
-// floors it at 1e-300: a lane measuring the moved particle against its own row has r2 = 0).
-//   r   = sqrt(r2) from v_rsq_f64 (2^-24) + one coupled Newton step + one residual correction (< 1 ulp)
-//   t   = r/dr,  i0 = int(t) = ix-1 of the reference,  f = fract(t)
-//   V   = F0 + f (F1-F0);   dV/dr * dr = (F1-Fm) + f ((Fp-F1) - (F0-Fm))   [= Fafter - Fbefore of interpolate.f90]
-//   force term (dV/dr)/r * x_k with 1/r = 2h from the same Newton step
-template <int DIM, int CLS, bool IS_OLD>
-__device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
-                                          double r2, bool in, const double (&d)[DIM], Acc<DIM, CLS> &A)
-{
-    const double y0 = __builtin_amdgcn_rsq(r2);
-    double g = r2 * y0;
-    double h = 0.5 * y0;
-    const double r0 = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r0, g);
-    h = __builtin_fma(h, r0, h);
-    const double d0 = __builtin_fma(-g, g, r2);
-    g = __builtin_fma(d0, h, g);
-    const double t  = g * P.rdr;
-    const int    it = (int)t;
-    const int    i0 = in ? it : VT.zc;
-    const double f  = __builtin_amdgcn_fract(t);
-    const double *V = VT.p + i0;
-    const double F0 = V[0], F1 = V[1];
-    const double v  = __builtin_fma(f, F1 - F0, F0);
-    if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
-    if (CLS == CLS_ODD) {
-        const double Fm = V[-1], Fp = V[2];
-        const double D  = __builtin_fma(f, (Fp - F1) - (F0 - Fm), F1 - Fm);
-        const double s  = D * (h * P.rdr);                                // ((Fafter-Fbefore)*0.5/dr) * (2h)
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            if (IS_OLD) A.fO[k] = __builtin_fma(s, d[k], A.fO[k]); else A.fN[k] = __builtin_fma(s, d[k], A.fN[k]);
-        }
-    }
-    if (CLS == CLS_END) {                                                 // LogWF stays in global memory (2 of 161 beads)
-        const double *U = WF + (in ? it : 0);
-        const double u0 = U[0], u1 = U[1];
-        const double u  = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;    // (1-f)*(-Inf) keeps the -Inf head (Q4)
-        if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
-    }
 }
 
 template <int DIM, int CLS>

@@ -378,4 +378,160 @@ __device__ __forceinline__ void item_eval(const DevParams &P, VTab VT, const dou
     else           item_direct<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
 }
 
+// Image of the VTable used by the branch-free evaluation (LDS copy in K1's pipe kernels, a global copy for
+// the device-resident sampler): [VT(0)] VT(0) .. VT(Nmax+1) [0 0 0 0]
+//   * the leading copy of VT(0) stands for the reference's clamp max(ix-2,0) at r < dr;
+//   * the trailing zeros are the "zero cell": a lane whose distance is outside the cutoff (or that has no
+//     partner) looks up cell zc = Nmax+3 and so contributes exactly 0 to every sum -- no weights, no selects
+//     on the results.
+struct PipeTab {
+    const double *p;      // -> VT(0) inside LDS
+    int zc;
+};
+
+// one distance, branch-free and weight-free (see PipeTab).  r2 must be finite and > 0 on every lane (the caller
+// floors it at 1e-300: a lane measuring the moved particle against its own row has r2 = 0).
+//   r   = sqrt(r2) from v_rsq_f64 (2^-24) + one coupled Newton step + one residual correction (< 1 ulp)
+//   t   = r/dr,  i0 = int(t) = ix-1 of the reference,  f = fract(t)
+//   V   = F0 + f (F1-F0);   dV/dr * dr = (F1-Fm) + f ((Fp-F1) - (F0-Fm))   [= Fafter - Fbefore of interpolate.f90]
+//   force term (dV/dr)/r * x_k with 1/r = 2h from the same Newton step
+template <int DIM, int CLS, bool IS_OLD>
+__device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                          double r2, bool in, const double (&d)[DIM], Acc<DIM, CLS> &A)
+{
+    const double y0 = __builtin_amdgcn_rsq(r2);
+    double g = r2 * y0;
+    double h = 0.5 * y0;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    const double d0 = __builtin_fma(-g, g, r2);
+    g = __builtin_fma(d0, h, g);
+    const double t  = g * P.rdr;
+    const int    it = (int)t;
+    const int    i0 = in ? it : VT.zc;
+    const double f  = __builtin_amdgcn_fract(t);
+    const double *V = VT.p + i0;
+    const double F0 = V[0], F1 = V[1];
+    const double v  = __builtin_fma(f, F1 - F0, F0);
+    if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
+    if (CLS == CLS_ODD) {
+        const double Fm = V[-1], Fp = V[2];
+        const double D  = __builtin_fma(f, (Fp - F1) - (F0 - Fm), F1 - Fm);
+        const double s  = D * (h * P.rdr);                                // ((Fafter-Fbefore)*0.5/dr) * (2h)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            if (IS_OLD) A.fO[k] = __builtin_fma(s, d[k], A.fO[k]); else A.fN[k] = __builtin_fma(s, d[k], A.fN[k]);
+        }
+    }
+    if (CLS == CLS_END) {                                                 // LogWF stays in global memory (2 of 161 beads)
+        const double *U = WF + (in ? it : 0);
+        const double u0 = U[0], u1 = U[1];
+        const double u  = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;    // (1-f)*(-Inf) keeps the -Inf head (Q4)
+        if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
+    }
+}
+
+
+// ---- branch-free item evaluation on a PipeTab (periodic systems, Np <= 256) --------------------------------
+// one pass of 64 partners: both distances as independent chains; rjm = this lane's partner coordinates
+template <int DIM, int CLS>
+__device__ __forceinline__ void pipe_pass_at(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                             int p, int j, const double (&rjm)[DIM], const double (&xn)[DIM],
+                                             const double (&xo)[DIM], Acc<DIM, CLS> &A)
+{
+    const bool valid = j < P.Np && j != p;                            // row p itself never enters (vpi_mod.f90:2699)
+    double dn[DIM], dold[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        // opaque per class: keeps the optimiser from hoisting the distance arithmetic of all passes above the
+        // class branch (it did: 24 live doubles more, spills)
+        double rj = rjm[k];
+        asm volatile("; class %1 pass" : "+v"(rj) : "n"(CLS));
+        dn[k] = xn[k] - rj; dold[k] = xo[k] - rj;
+    }
+    const double r2o = min_image_rn<DIM>(dold, P);
+    const double r2n = min_image_rn<DIM>(dn, P);
+    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
+    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
+    __builtin_amdgcn_sched_barrier(0);                                // two chains in flight (VGPRs)
+}
+
+template <int DIM, int CLS>
+__device__ __forceinline__ void item_direct_pipe(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                                 const double *__restrict__ S, int p, const double (&xn)[DIM],
+                                                 const double (&xo)[DIM], int lane, int b, double *red,
+                                                 double *out, double *parts)
+{
+    constexpr int MAXP = 4;
+    Acc<DIM, CLS> A;
+    double rj[MAXP][DIM];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        const int j = m * kWave + lane;
+        const int jj = j < P.Np ? j : 0;                              // in-bounds dummy for idle lanes
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) rj[m][k] = S[(size_t)k * P.NpPad + jj];
+    }
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) pipe_pass_at<DIM, CLS>(P, VT, WF, p, m * kWave + lane, rj[m], xn, xo, A);
+    finish_item<DIM, CLS>(P, lane, b, A, red, out, parts);
+}
+
+template <int DIM>
+__device__ __forceinline__ void item_eval_pipe(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                               const double *__restrict__ S, int p, int b, const double (&xn)[DIM],
+                                               const double (&xo)[DIM], int lane, double *red, double *out, double *parts)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       item_direct_pipe<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+    else if (endb) item_direct_pipe<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+    else           item_direct_pipe<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+}
+
+// split form (see item_pass_cls): ONE pass of an item, wave totals into tot8[]
+template <int DIM, int CLS>
+__device__ __forceinline__ void item_pass_pipe_cls(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                                   const double *__restrict__ S, int p, int m,
+                                                   const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                                   double *red, double *tot8)
+{
+    Acc<DIM, CLS> A;
+    const int j = m * kWave + lane;
+    const int jj = j < P.Np ? j : 0;
+    double rj[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + jj];
+    pipe_pass_at<DIM, CLS>(P, VT, WF, p, j, rj, xn, xo, A);
+    if (CLS == CLS_ODD) {
+        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
+        const double t = wave_reduce_lds<8>(v, red, lane);
+        if (lane < 8) tot8[lane] = t;
+    } else if (CLS == CLS_END) {
+        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
+        const double t = wave_reduce_lds<4>(v, red, lane);
+        if (lane < 4) tot8[lane] = t;
+    } else {
+        const double v[2] = {A.potN, A.potO};
+        const double t = wave_reduce_lds<2>(v, red, lane);
+        if (lane < 2) tot8[lane] = t;
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ void item_pass_pipe(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                               const double *__restrict__ S, int p, int b, int m,
+                                               const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                               double *red, double *tot8)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       item_pass_pipe_cls<DIM, CLS_ODD>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+    else if (endb) item_pass_pipe_cls<DIM, CLS_END>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+    else           item_pass_pipe_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
+}
+
 } // namespace pigs

@@ -64,7 +64,7 @@ struct SweepParams {
     double  delta_cm, log_cworm_density, rbin;
 };
 hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,
-                        const double *WF, uint32_t *rng, unsigned long long *counters, double *worm,
+                        const double *VTimg, const double *WF, uint32_t *rng, unsigned long long *counters, double *worm,
                         int *evlog, double *nrho, const double *dklog, hipStream_t st);
 hipError_t launch_slice_gather(const DevParams &P, const double *paths, int ib, double *out, hipStream_t st);
 size_t sweep_lds_bytes(const DevParams &P, const SweepParams &sp, int threads);
