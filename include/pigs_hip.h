@@ -63,8 +63,19 @@ int pigs_sync(pigs_ctx *ctx);
 /* The context's hipStream_t (as void*) so a host can order its own work against it. */
 int pigs_stream(pigs_ctx *ctx, void **hip_stream);
 
-/* Tuning knobs (performance only, never results beyond summation order).
- *   "k1_variant": 0 auto, 1 plain, 2 short-division, 3 +LDS table, 4 +compaction, 5 +both */
+/* Tuning knobs.
+ *   "k1_variant": which Delta-S kernel pigs_delta_action_* runs.
+ *        0  auto (default): periodic systems use the short arithmetic -- every per-pair term to ~1 ulp, cutoff
+ *           membership unchanged -- in the persistent LDS-table kernel (12) for launches of
+ *           >= 16 items per CU with Np <= 256, else in the plain grid (8 / 7); trapped systems use 2
+ *        1  plain statement of the reference's arithmetic          2  same terms bit for bit, short exact division
+ *        3  2 + table in LDS      4  2 + in-cutoff compaction      5  3 + 4        6  2 + prefetch
+ *        7  short arithmetic      8  7 + prefetch     9 / 10  7 / 8 + table in LDS
+ *        11 persistent LDS-table kernel, branch-free               12  11 + records / coordinates requested ahead
+ *      1-6 agree with each other up to the order of the sums; 7-12 likewise, and with 1-6 to ~1e-15 per term.
+ *      The environment variable PIGS_K1_VARIANT presets this key at pigs_ctx_create (test hook).
+ *   "sweep_threads": workgroup size of the device-resident sampler (256 / 512 / 1024); "sweep_debug": timing
+ *      experiments of that kernel (results become meaningless). */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */
