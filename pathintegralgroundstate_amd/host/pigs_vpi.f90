@@ -6,7 +6,7 @@
 ! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
 ! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
 ! system_mod.f90:15-34) plus one optional group of its own,
-!     &gpu  n_walkers = 1, device = 0, device_sampler = F, potential = 'aziz2'  /
+!     &gpu  n_walkers = 1, device = 0, device_sampler = F, potential = 'aziz2', k1_variant = 0  /
 ! (potential: aziz2 | lj | dipolar -- the reference selects it by editing system_mod.f90)
 ! (device_sampler = T: the whole MC step runs on the GPU, kernel K6 -- diagonal sector with
 ! sampling='bis' and CWorm = 0 only; otherwise the host-driven lock-step sampler is used)
@@ -35,7 +35,7 @@ program pigs_vpi
   real (kind=8)     :: density,dt,delta_cm,CWorm,Rm
   real (kind=8)     :: a_ho(3)
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
-  integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios
+  integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios,k1_variant
   logical           :: device_sampler,checkpointing
   integer(c_int32_t) :: rpos
   character (len=8) :: potential
@@ -46,7 +46,7 @@ program pigs_vpi
   namelist /wavefun/ Nmax,wf_table,v_table
   namelist /extpot/  a_ho
   namelist /jastrow/ Rm
-  namelist /gpu/     n_walkers,device,device_sampler,potential,checkpointing
+  namelist /gpu/     n_walkers,device,device_sampler,potential,checkpointing,k1_variant
 
   type(sampler_t)    :: s
   type(est_params)   :: ep
@@ -92,7 +92,7 @@ program pigs_vpi
   Nmax = 10000; wf_table = .false.; v_table = .false.
   CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
   delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
-  n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'; checkpointing = .true.
+  n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'; checkpointing = .true.; k1_variant = 0
 
   read (5,nml=system,iostat=ios);  rewind (5)
   read (5,nml=samp,iostat=ios);    rewind (5)
@@ -163,6 +163,8 @@ program pigs_vpi
   gp%dr = dr; gp%rcut2 = rcut2; gp%dt = dt; gp%Rm = Rm
   gp%Lbox = Lbox; gp%a_ho = a_ho
   call pigs_check(pigs_ctx_create(gp,VTable,LogWF,int(NW,c_int32_t),int(device,c_int32_t),ctx),'pigs_ctx_create')
+  ! k1_variant = 2 selects the Delta-S kernel that keeps the reference's rounding of every term (default 0: short arithmetic)
+  if (k1_variant/=0) call pigs_check(pigs_set_tuning(ctx,'k1_variant'//c_null_char,int(k1_variant,c_int32_t)),'pigs_set_tuning')
 
   call sampler_init(s,dim,Np,Nb,NW,trap,dt,density,CWorm,Lbox(1:dim),ctx)
   ep%dim = dim; ep%Np = Np; ep%Nbin = Nbin; ep%Nk = Nk; ep%Npw = Npw; ep%trap = trap

@@ -56,6 +56,18 @@ def test_gpu_front_end_matches_reference_program(exe, name, tmp_path):
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
 
 
+def test_gpu_front_end_exact_term_kernel(exe, tmp_path):
+    """&gpu k1_variant = 2: the Delta-S kernel that keeps the reference's rounding of every term gives the same
+    trajectory (bit-identical final worldline) as the default short arithmetic and the reference program."""
+    src = os.path.join(RUNS, "he4_worm_s1982")
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, k1_variant = 2\n/\n", str(tmp_path))
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert same_bits(got, want)
+    for f in ("e_vpi.out", "et_vpi.out"):
+        assert _close(tmp_path / f, os.path.join(src, f)), f
+
+
 def test_gpu_lockstep_walkers(exe, tmp_path):
     base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
     _run(exe, base + "&gpu\n n_walkers = 3, device = 0\n/\n", str(tmp_path))
