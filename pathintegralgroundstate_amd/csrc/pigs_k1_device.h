@@ -119,7 +119,7 @@ __device__ __forceinline__ void finish_item(const DevParams &P, int lane, int b,
         dPot = read_lane(t, 0) - read_lane(t, 1);
     }
     if (lane == 0) {
-        *out = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);      // :2527
+        *out = -dPsi + green_function_action(b, P.Nb, P.dt, dPot, dF2);      // :2527
         if (parts) {
             parts[0] = dPot;
             parts[1] = dF2;
@@ -279,10 +279,12 @@ __device__ __forceinline__ double item_finish_split(const DevParams &P, int b, i
 {
     const bool odd  = (b & 1) != 0;
     const bool endb = (b == 0) || (b == 2 * P.Nb);
+    // all eight columns are summed (static register indexing); the class decides which ones mean anything
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const int nv = odd ? 8 : (endb ? 4 : 2);
-    for (int m = 0; m < npass; ++m)
-        for (int q = 0; q < nv; ++q) s[q] = s[q] + tot[m * 8 + q];
+    for (int m = 0; m < npass; ++m) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] = s[q] + tot[m * 8 + q];
+    }
     double dF2 = 0.0, dPsi = 0.0;
     const double dPot = s[0] - s[1];
     if (odd) {
@@ -293,7 +295,7 @@ __device__ __forceinline__ double item_finish_split(const DevParams &P, int b, i
     } else if (endb) {
         dPsi = s[2] - s[3];
     }
-    return -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);
+    return -dPsi + green_function_action(b, P.Nb, P.dt, dPot, dF2);
 }
 
 // one item in two passes: (1) all distances + cutoff, in-cutoff (partner, new|old) codes compacted
