@@ -260,7 +260,7 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
         return PIGS_OK;
     }
     if (!strcmp(key, "sweep_threads")) {
-        if (value != 256 && value != 512 && value != 1024) return fail(PIGS_ERR_ARG, "sweep_threads=%d", value);
+        if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(PIGS_ERR_ARG, "sweep_threads=%d", value);
         c->sweep_threads = value;
         return PIGS_OK;
     }
@@ -543,7 +543,10 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     c->cm_freq = sp->CMFreq;
     // one workgroup per walker: 16 waves when every walker gets a CU of its own, 4 waves (3 workgroups
     // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
+    // ... and 12 waves with the VTable image in LDS when that fits (periodic systems)
     c->sweep_threads = c->n_walkers > 256 ? 256 : 1024;
+    if (c->sweep_threads == 1024 && !c->P.trap && !(c->P.Nmax & 1) && sweep_lds_bytes(c->P, c->sweep, 768) <= 160 * 1024)
+        c->sweep_threads = 768;
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) c->sweep_threads = 512;
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
     const size_t W = c->n_walkers;
