@@ -117,6 +117,24 @@ def test_gpu_front_end_device_sampler_worm_sector(exe, tmp_path):
         assert open(tmp_path / f"perm_vpi.w{w:04d}.out").read().split() == open(os.path.join(src, "fort.99")).read().split(), w
 
 
+def test_gpu_front_end_device_sampler_stock_input(exe, tmp_path):
+    """device_sampler = T on the reference's stock vpi.in (shortened): N=64, Nb=32, Lstag=32 -- open/close and
+    half-chain staging proposals of up to 96 Gaussians, several look-ahead refills of the random stream per
+    stage -- against the reference program's files."""
+    src = os.path.join(RUNS, "he4_stock_short")
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = T\n/\n",
+         str(tmp_path))
+    assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert np.mean(np.abs(got - want) < 1e-9) > 0.999, np.max(np.abs(got - want))
+    for f in ("e_vpi.out", "et_vpi.out"):
+        if os.path.getsize(os.path.join(src, f)):
+            assert _close(tmp_path / f, os.path.join(src, f)), f
+    assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+    assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
+
+
 @pytest.mark.parametrize("name", ["he4_cworm0", "ho1d_n2"])
 def test_gpu_front_end_device_sampler_staging_movers(exe, name, tmp_path):
     """device_sampler = T with sampling = 'sta' (MoveHead, MoveTail, Staging on the GPU): the 2D periodic run with
