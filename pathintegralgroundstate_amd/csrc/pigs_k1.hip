@@ -272,40 +272,50 @@ __device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__r
 
 __device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt + 6) * sizeof(double) + 15) & ~(size_t)15; }
 
-__device__ __forceinline__ PipeTab pipe_stage_table(unsigned char *smem, const double *__restrict__ VTg, int nt)
+// Staging the table image: 16-byte copies (hipMalloc'ed table, tab = smem + 16: both 16-byte aligned), in two
+// steps so that a kernel can put its first HBM requests BETWEEN them -- the table loads (L2 hits) are issued first
+// and, vmcnt being in order, are complete long before the slice loads queued behind them, so the LDS writes and
+// the workgroup barrier do not wait for HBM.  (A plain copy loop compiles to load - wait - write per iteration:
+// five serialized L2 round trips.)
+constexpr int kTabU = 5;
+struct TabRegs { double2 v[kTabU]; };
+
+__device__ __forceinline__ void pipe_table_load(const double *__restrict__ VTg, int nt, TabRegs &r)
+{
+    const double2 *src = reinterpret_cast<const double2 *>(VTg);
+    const int n2 = nt / 2;
+#pragma unroll
+    for (int u = 0; u < kTabU; ++u) {
+        const int idx = u * (int)blockDim.x + (int)threadIdx.x;
+#ifdef PIGS_EXPERIMENT_NO_STAGE
+        r.v[u] = double2{0.0, 0.0};
+#else
+        r.v[u] = src[idx < n2 ? idx : n2 - 1];                  // out-of-range threads duplicate the last element
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);                          // keep the loads up here (the scheduler sinks them to their stores)
+}
+
+__device__ __forceinline__ PipeTab pipe_table_store(unsigned char *smem, const double *__restrict__ VTg, int nt,
+                                                    const TabRegs &r)
 {
     double *base = reinterpret_cast<double *>(smem);          // base[1] = leading copy, base[2..] = table
     double *tab  = base + 2;
-    {
-        // 16-byte copies (hipMalloc'ed table, tab = smem + 16: both 16-byte aligned)
-        // all of a thread's loads are issued before its first LDS write (a plain copy loop compiles to
-        // load - wait - write per iteration: five serialized L2 round trips, 2 us)
-        const double2 *src = reinterpret_cast<const double2 *>(VTg);
-        double2 *dst = reinterpret_cast<double2 *>(tab);
-        constexpr int U = 5;
-        const int n2 = nt / 2;
-#ifdef PIGS_EXPERIMENT_NO_STAGE
-        for (int base = 0; base < 0; base += U * (int)blockDim.x) {
-#else
-        for (int base = 0; base < n2; base += U * (int)blockDim.x) {
-#endif
-            double2 v[U];
+    const double2 *src = reinterpret_cast<const double2 *>(VTg);
+    double2 *dst = reinterpret_cast<double2 *>(tab);
+    const int n2 = nt / 2;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
-                v[u] = src[idx < n2 ? idx : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
-                if (idx < n2) dst[idx] = v[u];
-            }
-        }
-        if (threadIdx.x == 0) {
-            if (nt & 1) tab[nt - 1] = VTg[nt - 1];
-            base[0] = 0.0; base[1] = VTg[0];
-            tab[nt] = 0.0; tab[nt + 1] = 0.0; tab[nt + 2] = 0.0; tab[nt + 3] = 0.0;
-        }
+    for (int u = 0; u < kTabU; ++u) {
+        // unconditional (clamped) stores: a conditional store is a basic block of its own and the optimiser
+        // sinks the load into it -- load, wait, write, five times in a row
+        const int idx = u * (int)blockDim.x + (int)threadIdx.x;
+        dst[idx < n2 ? idx : n2 - 1] = r.v[u];
+    }
+    for (int idx = kTabU * (int)blockDim.x + (int)threadIdx.x; idx < n2; idx += (int)blockDim.x) dst[idx] = src[idx];   // longer tables
+    if (threadIdx.x == 0) {
+        if (nt & 1) tab[nt - 1] = VTg[nt - 1];
+        base[0] = 0.0; base[1] = VTg[0];
+        tab[nt] = 0.0; tab[nt + 1] = 0.0; tab[nt + 2] = 0.0; tab[nt + 3] = 0.0;
     }
     return PipeTab{tab, nt + 1};
 }
@@ -357,11 +367,12 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
     const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     int k = wid;
     ItemRec<DIM> cur;
-    // the first item's slice is requested before the table is staged: the two latencies overlap
-    if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
-
     const int nt = P.Nmax + 2;
-    const PipeTab VT = pipe_stage_table(smem, VTg, nt);
+    TabRegs treg;
+    pipe_table_load(VTg, nt, treg);
+    // the first item's slice is requested while the table is on its way: the two latencies overlap
+    if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
+    const PipeTab VT = pipe_table_store(smem, VTg, nt, treg);
     if (threadIdx.x == 0) next_local = 16;
     double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
@@ -549,6 +560,9 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
     int k_cur = wid, k_nx = wid + 16;
     ItemMeta<DIM> cur;
     PipeState<DIM> st;
+    const int nt = P.Nmax + 2;
+    TabRegs treg;
+    pipe_table_load(VTg, nt, treg);                              // L2 hits, issued ahead of the HBM requests below
     {
         const ItemRaw r0 = pipe2_request<DIM>((int)blockIdx.x + (k_cur < n_local ? k_cur : 0) * (int)gridDim.x,
                                               walker, ipv, ibv, xnew, xold, lane);
@@ -559,8 +573,7 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
         pipe2_load<DIM>(P, cur.S, 1, lane, st.a1);
     }
 
-    const int nt = P.Nmax + 2;
-    const PipeTab VT = pipe_stage_table(smem, VTg, nt);
+    const PipeTab VT = pipe_table_store(smem, VTg, nt, treg);
     if (threadIdx.x == 0) next_local = 32;
     double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
