@@ -272,49 +272,37 @@ __device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__r
 
 __device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt + 6) * sizeof(double) + 15) & ~(size_t)15; }
 
-// Staging the table image: 16-byte copies (hipMalloc'ed table, tab = smem + 16: both 16-byte aligned), in two
-// steps so that a kernel can put its first HBM requests BETWEEN them -- the table loads (L2 hits) are issued first
-// and, vmcnt being in order, are complete long before the slice loads queued behind them, so the LDS writes and
-// the workgroup barrier do not wait for HBM.  (A plain copy loop compiles to load - wait - write per iteration:
-// five serialized L2 round trips.)
+// Staging the table image with the LDS-DMA form of the global load (global_load_lds_dwordx4: 16 bytes per lane
+// straight into LDS at M0 + lane*16, no VGPRs, no ds_write): issued as the very first instructions of the
+// kernel, ahead of the HBM requests of the first items; completion is a vmcnt matter, so ONE `s_waitcnt vmcnt(0)`
+// before the workgroup barrier covers it (the first item needs its own loads by then anyway).  A wave issues the
+// chunk [u*blockDim + wid*64, +64) only if it starts inside the table; lanes past the end are masked off.
 constexpr int kTabU = 5;
-struct TabRegs { double2 v[kTabU]; };
 
-__device__ __forceinline__ void pipe_table_load(const double *__restrict__ VTg, int nt, TabRegs &r)
+__device__ __forceinline__ void pipe_table_dma_issue(unsigned char *smem, const double *__restrict__ VTg, int nt, int wid, int lane)
 {
+#ifndef PIGS_EXPERIMENT_NO_STAGE
     const double2 *src = reinterpret_cast<const double2 *>(VTg);
     const int n2 = nt / 2;
-#pragma unroll
-    for (int u = 0; u < kTabU; ++u) {
-        const int idx = u * (int)blockDim.x + (int)threadIdx.x;
-#ifdef PIGS_EXPERIMENT_NO_STAGE
-        r.v[u] = double2{0.0, 0.0};
-#else
-        r.v[u] = src[idx < n2 ? idx : n2 - 1];                  // out-of-range threads duplicate the last element
-#endif
+    for (int cb = wid * kWave; cb < n2; cb += (int)blockDim.x) {      // wave-uniform
+        const int idx = cb + lane;
+        auto *l = reinterpret_cast<__attribute__((address_space(3))) void *>(
+            (__attribute__((address_space(3))) unsigned char *)smem + 16 + (size_t)cb * 16);
+        // lanes past the end of the table are masked off (EXEC): they neither load nor write their LDS slot
+        if (idx < n2) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + idx), l, 16, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);                          // keep the loads up here (the scheduler sinks them to their stores)
+#endif
 }
 
-__device__ __forceinline__ PipeTab pipe_table_store(unsigned char *smem, const double *__restrict__ VTg, int nt,
-                                                    const TabRegs &r)
+// after this and a workgroup barrier the image is complete
+__device__ __forceinline__ PipeTab pipe_table_dma_finish(unsigned char *smem, const double *__restrict__ VTg, int nt)
 {
     double *base = reinterpret_cast<double *>(smem);          // base[1] = leading copy, base[2..] = table
     double *tab  = base + 2;
-    const double2 *src = reinterpret_cast<const double2 *>(VTg);
-    double2 *dst = reinterpret_cast<double2 *>(tab);
-    const int n2 = nt / 2;
-#pragma unroll
-    for (int u = 0; u < kTabU; ++u) {
-        // unconditional (clamped) stores: a conditional store is a basic block of its own and the optimiser
-        // sinks the load into it -- load, wait, write, five times in a row
-        const int idx = u * (int)blockDim.x + (int)threadIdx.x;
-        dst[idx < n2 ? idx : n2 - 1] = r.v[u];
-    }
-    for (int idx = kTabU * (int)blockDim.x + (int)threadIdx.x; idx < n2; idx += (int)blockDim.x) dst[idx] = src[idx];   // longer tables
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
         if (nt & 1) tab[nt - 1] = VTg[nt - 1];
-        base[0] = 0.0; base[1] = VTg[0];
+        base[0] = 0.0; base[1] = tab[0];                          // wave 0 staged chunk 0 itself: tab[0] has landed
         tab[nt] = 0.0; tab[nt + 1] = 0.0; tab[nt + 2] = 0.0; tab[nt + 3] = 0.0;
     }
     return PipeTab{tab, nt + 1};
@@ -368,11 +356,10 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe(
     int k = wid;
     ItemRec<DIM> cur;
     const int nt = P.Nmax + 2;
-    TabRegs treg;
-    pipe_table_load(VTg, nt, treg);
+    pipe_table_dma_issue(smem, VTg, nt, wid, lane);
     // the first item's slice is requested while the table is on its way: the two latencies overlap
     if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
-    const PipeTab VT = pipe_table_store(smem, VTg, nt, treg);
+    const PipeTab VT = pipe_table_dma_finish(smem, VTg, nt);
     if (threadIdx.x == 0) next_local = 16;
     double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
@@ -561,8 +548,7 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
     ItemMeta<DIM> cur;
     PipeState<DIM> st;
     const int nt = P.Nmax + 2;
-    TabRegs treg;
-    pipe_table_load(VTg, nt, treg);                              // L2 hits, issued ahead of the HBM requests below
+    pipe_table_dma_issue(smem, VTg, nt, wid, lane);              // L2 hits, issued ahead of the HBM requests below
     {
         const ItemRaw r0 = pipe2_request<DIM>((int)blockIdx.x + (k_cur < n_local ? k_cur : 0) * (int)gridDim.x,
                                               walker, ipv, ibv, xnew, xold, lane);
@@ -573,7 +559,7 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
         pipe2_load<DIM>(P, cur.S, 1, lane, st.a1);
     }
 
-    const PipeTab VT = pipe_table_store(smem, VTg, nt, treg);
+    const PipeTab VT = pipe_table_dma_finish(smem, VTg, nt);
     if (threadIdx.x == 0) next_local = 32;
     double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
