@@ -358,9 +358,13 @@ __host__ __device__ inline double green_function(int opt, int ib, int Nb, double
 // GreenFunction(0, ...) for the kernels' epilogues: the same expressions with the divisions by 3 and 6 done as
 // exact short divisions (div_by with RN(1/3), RN(1/6): bit-identical to `/`, checked over 3e8 operands) -- the
 // IEEE expansions were ~500 dependent cycles at the end of every item and of every sampler stage.
-__device__ __forceinline__ double green_function_action(int ib, int Nb, double dt, double Pot, double F2)
+__device__ __forceinline__ double green_function_action(int ib, int Nb, double dt_in, double Pot, double F2)
 {
     constexpr double r3 = 1.0 / 3.0, r6 = 1.0 / 6.0;
+    // dt made opaque: hoisted out of a persistent kernel's item loop, the products 2*dt, 4*dt, dt*dt each cost a
+    // VGPR pair (and spilled at the 128-VGPR budget of K1's pipe kernels); recomputing them per item is free
+    double dt = dt_in;
+    asm volatile("" : "+v"(dt));
     if (ib == 0 || ib == 2 * Nb) return div_by(dt * Pot, 3.0, r3);
     if ((ib & 1) == 0)           return div_by(2.0 * dt * Pot, 3.0, r3);
     const double Vc = Pot + div_by(dt * dt * F2, 6.0, r6);

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
     while (k_cur < n_local) {                                   // wave-uniform
         const int it = (int)blockIdx.x + k_cur * (int)gridDim.x;
         double *o = out + it;
-        double *q = parts ? parts + (size_t)it * 3 : nullptr;
+        double *q = nullptr;                                     // the (DeltaPot, DeltaF2, DeltaPsi) diagnostic runs on the plain grid
         if (!cur.ok) {
             // malformed item: NaN result; keep the pipeline moving without evaluating anything
             if (lane == 0) *o = __builtin_nan("");
@@ -684,6 +684,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
     if (variant == K1_FAST_PREFETCH && P.Np > 256) variant = K1_FAST;
     if ((variant == K1_FAST_LDS || variant == K1_FAST_LDS_PREFETCH) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
     if ((variant == K1_PIPE || variant == K1_PIPE2) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
+    if (variant == K1_PIPE2 && parts) variant = K1_FAST_PREFETCH;      // pipe2 has no registers to spare for the diagnostic output
     if (variant >= K1_FAST && P.trap) variant = K1_V2;   // no cutoff in the trap: exact path
     hipError_t e = hipSuccess;
     switch (variant) {
