@@ -729,7 +729,7 @@ int pigs_potential_energy_slice(pigs_ctx *c, int32_t walker, int32_t ib, int32_t
     hipStream_t s = c->stream;
     HIPCHK(hipMemcpyAsync(c->d_slotw.p, &walker, sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_slotb.p, &ib, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, 1, c->d_slotw.p, c->d_slotb.p, want_F2 ? 2 : 0, 0, c->d_slices.p, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, c->d_VTimg, 1, c->d_slotw.p, c->d_slotb.p, want_F2 ? 2 : 0, 0, c->d_slices.p, s));
     double h[3];
     HIPCHK(hipMemcpyAsync(h, c->d_slices.p, sizeof h, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -757,7 +757,7 @@ int pigs_therm_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, doub
     hipStream_t s = c->stream;
     HIPCHK(hipMemcpyAsync(c->d_slotw.p, sw.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_slotb.p, sb.data(), nslot * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, (int)nslot, c->d_slotw.p, c->d_slotb.p, 1, 1, c->d_slices.p, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, c->d_VTimg, (int)nslot, c->d_slotw.p, c->d_slotb.p, 1, 1, c->d_slices.p, s));
     HIPCHK(launch_therm_combine(c->P, n, c->d_slices.p, c->d_res.p, c->d_res.p + n, c->d_res.p + 2 * (size_t)n, s));
     HIPCHK(hipMemcpyAsync(E, c->d_res.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(Ec, c->d_res.p + n, n * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -31,7 +31,7 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
                                const int32_t *ip, const int32_t *ib, const double *xnew,
                                const double *xold, double *out, double *parts, hipStream_t st);
 
-hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT,
+hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT, const double *VTimg,
                                int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
                                int force_mode, int want_spring, double *out, hipStream_t st);
 

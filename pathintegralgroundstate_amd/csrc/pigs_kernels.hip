@@ -10,6 +10,7 @@
 //
 // Compile with -ffp-contract=off (per-term bit parity with the reference, see pigs_device.h).
 #include "pigs_device.h"
+#include "pigs_k1_device.h"
 #include "pigs_kernels.h"
 
 namespace pigs {
@@ -143,6 +144,110 @@ __global__ __launch_bounds__(256) void k_slice_energy(
         out[(size_t)slot * 3 + 0] = a;
         out[(size_t)slot * 3 + 1] = want_f ? c : 0.0;
         out[(size_t)slot * 3 + 2] = e;
+    }
+}
+
+// =====================================================================================
+// K2 for periodic systems with Np <= 256 and many slices (ThermEnergy of many walkers): persistent, ONE
+// 1024-thread workgroup per CU that keeps the VTable image in LDS (the per-slice kernel's table gather kept
+// the texture addresser busier than the VALU) and walks four slices at a time, one per 256-thread group;
+// same per-thread ownership of particle i, same partner order for F_i, same ring walk on V-only slices,
+// short arithmetic with the zero cell (pigs_k1_device.h PipeTab): no divergent cutoff branch.
+// =====================================================================================
+template <int DIM>
+__global__ __launch_bounds__(1024) void k_slice_energy_lds(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTimg,
+    int n_slots, const int32_t *__restrict__ slot_walker, const int32_t *__restrict__ slot_ib,
+    int force_mode, int want_spring, double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, gw = (tid >> 6) & 3;
+    const int nimg = P.Nmax + 2 + 6;
+    double *img = reinterpret_cast<double *>(smem);
+    const size_t img_bytes = ((size_t)nimg * 8 + 15) & ~(size_t)15;
+    double *sxall = reinterpret_cast<double *>(smem + img_bytes);
+    double *sx  = sxall + (size_t)grp * DIM * P.NpPad;
+    double *red = sxall + (size_t)4 * DIM * P.NpPad + grp * 12;       // 3 x 4 waves per group
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(VTimg);
+        double2 *dst = reinterpret_cast<double2 *>(img);
+        for (int q = tid; q < nimg / 2; q += 1024) dst[q] = src[q];
+    }
+    const PipeTab VT{img + 2, P.Nmax + 3};
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+
+    for (int base = blockIdx.x * 4; base < n_slots; base += gridDim.x * 4) {      // workgroup-uniform
+        const int slot = base + grp;
+        const bool live = slot < n_slots;
+        const int w = live ? slot_walker[slot] : 0;
+        const int b = live ? slot_ib[slot] : 0;
+        const double *S = paths + ((size_t)w * P.M + b) * sl;
+        const bool want_f = force_mode == 2 || (force_mode == 1 && (b & 1));
+        __syncthreads();                                                          // previous slices consumed (and, first time, the table staged)
+        for (int q = t; q < DIM * P.NpPad; q += 256) sx[q] = S[q];
+        __syncthreads();
+        double pot = 0.0, f2 = 0.0, spring = 0.0;
+        const int i = t;
+        if (live && i < P.Np) {
+            double xi[DIM], F[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) { xi[k] = sx[k * P.NpPad + i]; F[k] = 0.0; }
+            double poti = 0.0;
+            if (want_f) {
+                // every partner, in index order (F_i summed as the reference does); the pair (i,i) has r2 = 0:
+                // floored and sent to the zero cell
+                for (int j = 0; j < P.Np; ++j) {
+                    double d[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
+                    const double r2 = min_image_rn<DIM>(d, P);
+                    const bool in = j != i && r2 <= P.rcut2;
+                    const FCell C = fcell_setup(__builtin_fmax(r2, 1e-300), P);
+                    const double *V = VT.p + (in ? C.i0 : VT.zc);
+                    const double Fm = V[-1], F0 = V[0], F1 = V[1], Fp = V[2];
+                    poti = poti + __builtin_fma(C.f, F1 - F0, F0);
+                    const double D = __builtin_fma(C.f, (Fp - F1) - (F0 - Fm), F1 - Fm);
+                    const double sc = D * (C.rinv * P.hrdr);
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) F[k] = __builtin_fma(sc, d[k], F[k]);
+                }
+                poti = 0.5 * poti;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) f2 = f2 + F[k] * F[k];
+            } else {
+                const int h = (P.Np & 1) ? (P.Np - 1) / 2 : (i < P.Np / 2 ? P.Np / 2 : P.Np / 2 - 1);
+                int j = i;
+                for (int q = 0; q < h; ++q) {
+                    j = j + 1 == P.Np ? 0 : j + 1;
+                    double d[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) d[k] = xi[k] - sx[k * P.NpPad + j];
+                    const double r2 = min_image_rn<DIM>(d, P);
+                    const FCell C = fcell_setup(__builtin_fmax(r2, 1e-300), P);
+                    const double *V = VT.p + (r2 <= P.rcut2 ? C.i0 : VT.zc);
+                    poti = poti + __builtin_fma(C.f, V[1] - V[0], V[0]);
+                }
+            }
+            pot = poti;
+            if (want_spring) {                                    // sample_mod.f90:359-380 (Q8)
+                const double *S1 = S + sl;
+                double d[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) d[k] = xi[k] - S1[(size_t)k * P.NpPad + i];
+                const double r2 = min_image<DIM>(d, P);
+                if (r2 <= P.rcut2) spring = 0.5 * r2 / (P.dt * P.dt);
+            }
+        }
+        pot = wave_sum(pot); f2 = wave_sum(f2); spring = wave_sum(spring);
+        if (lane == 0) { red[gw] = pot; red[4 + gw] = f2; red[8 + gw] = spring; }
+        __syncthreads();
+        if (live && t == 0) {
+            double a = 0.0, c = 0.0, e = 0.0;
+            for (int q = 0; q < 4; ++q) { a += red[q]; c += red[4 + q]; e += red[8 + q]; }
+            out[(size_t)slot * 3 + 0] = a;
+            out[(size_t)slot * 3 + 1] = want_f ? c : 0.0;
+            out[(size_t)slot * 3 + 2] = e;
+        }
     }
 }
 
@@ -383,11 +488,36 @@ static int slice_block(const DevParams &P)
     return t > 256 ? 256 : t;
 }
 
-hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT,
+hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT, const double *VTimg,
                                int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
                                int force_mode, int want_spring, double *out, hipStream_t st)
 {
     if (n_slots <= 0) return hipSuccess;
+    // many slices of a periodic system: the persistent LDS-table kernel (one workgroup per CU, 4 slices at a time)
+    {
+        const size_t lds = ((((size_t)P.Nmax + 8) * 8 + 15) & ~(size_t)15) + ((size_t)4 * P.dim * P.NpPad + 48) * sizeof(double);
+        int dev = 0, ncu = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ncu = pr.multiProcessorCount;
+        if (!P.trap && VTimg && P.Np <= 256 && !(P.Nmax & 1) && lds <= 160 * 1024 && n_slots >= 8 * ncu) {
+            int blocks = (n_slots + 3) / 4;
+            if (blocks > ncu) blocks = ncu;
+            hipError_t e = hipSuccess;
+#define CALLL(D)                                                                                          \
+    do {                                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_slice_energy_lds<D>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        if (e == hipSuccess)                                                                              \
+            hipLaunchKernelGGL((k_slice_energy_lds<D>), dim3(blocks), dim3(1024), lds, st, P, paths,      \
+                               VTimg, n_slots, slot_walker, slot_ib, force_mode, want_spring, out);       \
+    } while (0)
+            if (P.dim == 1) CALLL(1); else if (P.dim == 2) CALLL(2); else CALLL(3);
+#undef CALLL
+            if (e != hipSuccess) return e;
+            return hipGetLastError();
+        }
+    }
     const int bs = slice_block(P);
     const size_t lds = ((size_t)P.dim * P.NpPad + 3 * (bs / 64)) * sizeof(double);
 #define CALL(D, T)                                                                       \

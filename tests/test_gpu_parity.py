@@ -512,3 +512,28 @@ def test_edge_shapes_all_kernels(gpu_lib, oracle, kw):
         p = np.array(oracle.potential_energy(S, VT, Paths[1][ib_], True))
         if np.all(np.isfinite(p)):
             assert _close_rel(pot[ib_], p, 1e-9)
+
+
+def test_therm_energy_many_walkers_lds_table_kernel(gpu_lib, oracle):
+    """ThermEnergy of 16 walkers at N=64, Nb=80: 2 560 slices in one launch take the persistent LDS-table form of K2
+    (>= 8 slices per CU); every walker against the oracle, and against the per-slice kernel through the test hook."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(dim=3, Np=64, Nb=80)
+    cfg = SystemConfig(dim=3, Np=64, Nb=80)
+    VT, WF = oracle.tables(S)
+    W = 16
+    Paths = _worldlines(oracle, S, W, 31, 0.1)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        E, Ec, Ep = ctx.therm_energy_batch()
+        sub = ctx.therm_energy_batch(walkers=[3, 7])               # 320 slices: the per-slice kernel
+        pot_f2 = [ctx.potential_energy_slice(5, ib, True) for ib in (0, 1, 80, 159)]
+    for k in range(W):
+        te = oracle.therm_energy(S, VT, Paths[k])
+        assert _close_rel([E[k], Ec[k], Ep[k]], te), k
+    assert _close_rel([sub[0][0], sub[1][0], sub[2][0]], [E[3], Ec[3], Ep[3]])
+    assert _close_rel([sub[0][1], sub[1][1], sub[2][1]], [E[7], Ec[7], Ep[7]])
+    for (pot, f2), ib in zip(pot_f2, (0, 1, 80, 159)):
+        want = oracle.potential_energy(S, VT, Paths[5][ib], True)
+        assert _close_rel([pot, f2], want)
