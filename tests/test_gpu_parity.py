@@ -537,3 +537,45 @@ def test_therm_energy_many_walkers_lds_table_kernel(gpu_lib, oracle):
     for (pot, f2), ib in zip(pot_f2, (0, 1, 80, 159)):
         want = oracle.potential_energy(S, VT, Paths[5][ib], True)
         assert _close_rel([pot, f2], want)
+
+
+@pytest.mark.parametrize("kw,W", [(dict(dim=2, Np=37, Nb=40, density=0.05), 64), (dict(dim=1, Np=11, Nb=24, density=0.2), 48),
+                                  (dict(dim=3, Np=200, Nb=16, density=0.365), 80)])
+def test_persistent_kernels_on_ragged_shapes(gpu_lib, oracle, kw, W):
+    """The persistent LDS-table kernels (K1 pipe / pipe2, K2 LDS form) on shapes they were not tuned for: 1D / 2D,
+    particle counts that do not fill a wave or a pass, short chains.  DeltaS against the oracle, ThermEnergy of every
+    walker against the oracle."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(**kw)
+    cfg = SystemConfig(**kw)
+    VT, WF = oracle.tables(S)
+    Paths = _worldlines(oracle, S, W, 3, 0.1)
+    rng = np.random.default_rng(S.Np)
+    n = 24000
+    w, ip, ib, xnew, xold = _random_batch(rng, S, Paths, n, 0.1)
+    sel = np.arange(0, n, 17)
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w[sel], ip[sel], ib[sel], xnew[sel], xold[sel])
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        got = {}
+        for v in (11, 12, 0, 2):
+            ctx.set_tuning("k1_variant", v)
+            got[v] = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+        ctx.set_tuning("k1_variant", 0)
+        E, Ec, Ep = ctx.therm_energy_batch()
+    assert W * 2 * S.Nb >= 8 * 256                                   # enough slices for the LDS form of K2
+    sv = np.zeros(len(sel)); sf = np.zeros(len(sel)); su = np.zeros(len(sel))
+    for k in range(W):
+        m = w[sel] == k
+        if m.any():
+            sv[m], sf[m], su[m] = term_scales(S, VT, WF, Paths[k], ip[sel][m], ib[sel][m], xnew[sel][m], xold[sel][m])
+    tol = delta_s_tolerance(S, sv, sf, su)
+    fin = np.isfinite(want)
+    for v in (11, 12, 0, 2):
+        assert np.array_equal(np.isnan(got[v][sel]), np.isnan(want)), v
+        assert np.all(np.abs(got[v][sel] - want)[fin] <= tol[fin]), (v, np.max((np.abs(got[v][sel] - want) / tol)[fin]))
+    for k in range(0, W, 7):
+        te = oracle.therm_energy(S, VT, Paths[k])
+        if np.all(np.isfinite(te)):
+            assert _close_rel([E[k], Ec[k], Ep[k]], te), k
