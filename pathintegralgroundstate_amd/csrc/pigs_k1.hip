@@ -6,18 +6,21 @@
 //
 // Work decomposition: ONE wave64 per item (an item's 255 partners are 4 lane-strided passes
 // over one contiguous 6 KB SoA slice: 512-B coalesced loads per coordinate); no workgroup
-// barrier anywhere in the item loop.  The kernel is instruction-issue bound on fp64 VALU
-// (sqrt + up to 8 divisions per distance), not on HBM, so the variants attack instruction
-// count and lane utilisation:
+// barrier anywhere in the item loop.  Kernels in this file, in the order they were written (each one
+// selectable with pigs_set_tuning("k1_variant"), measurements in DESIGN.md section 4 and profiles/):
 //   v1  plain statement (IEEE `/`, sqrt(), tables gathered from global memory)
-//   v2  exact short division / fused sqrt+1/r (pigs_device.h), one shared butterfly for all
+//   v2  exact short division / fused sqrt+1/r (pigs_device.h), one LDS-transpose reduction for all
 //       accumulators; template flags:
 //         LDSTAB   VTable resident in LDS (80 KB): gathers become ds_read_b64
 //         COMPACT  two passes: (1) distances + cutoff test for all partners, in-cutoff
 //                  (partner, new|old) codes compacted through LDS with ballot/mbcnt;
-//                  (2) the expensive part runs on dense lanes only (44 % of the distance
-//                  evaluations are outside rcut and would otherwise idle their lanes).
-// Every variant sums bit-identical per-pair terms; only the summation order differs.
+//                  (2) the expensive part runs on dense lanes only
+//         PREFETCH all partner loads of an item issued up front
+//         FAST     the short arithmetic (~1 ulp per term, same cutoff decisions; pigs_device.h FastTab)
+//       v1 and v2 without FAST sum bit-identical per-pair terms; only the summation order differs.
+//   pipe / pipe2  persistent, one 1024-thread workgroup per CU, table image with its zero cell in LDS,
+//       branch-free short arithmetic, per-workgroup item queue; pipe2 (the default for large launches of a
+//       periodic system) also requests item records and partner coordinates ahead of their use.
 #include "pigs_device.h"
 #include "pigs_k1_device.h"
 #include "pigs_kernels.h"
