@@ -1,10 +1,13 @@
 // pigs_device.h -- device-side primitives of the PIGS hot path for gfx950 (wave64).
 //
-// fp64 VALU only (no MFMA: there is no dense contraction on this path).  Every
-// expression keeps the reference's operand order and is compiled with
-// -ffp-contract=off, so each per-pair TERM is bit-identical to the reference's; only
-// the order in which terms are summed differs (lane-strided partial sums + a fixed
-// butterfly, deterministic run to run, no atomics).
+// fp64 VALU only (no MFMA: there is no dense contraction on this path), compiled with -ffp-contract=off
+// (every fused multiply-add is written out).  Two forms of the pair arithmetic live here:
+//   * exact-term: every expression keeps the reference's operand order and rounding, so each per-pair TERM is
+//     bit-identical to the reference's; only the order in which terms are summed differs (lane-strided partial
+//     sums + a fixed reduction, deterministic run to run, no atomics).  min_image*, lerp_setup / interp*, and
+//     the exact short forms div_by / sqrt_rinv / flerp_* / finterp*.
+//   * short: the same quantities to ~1 ulp per term with the cutoff decision unchanged (min_image_rn, fcell_setup,
+//     FastTab; the branch-free PipeTab form is in pigs_k1_device.h) -- the default for periodic systems.
 //
 // Reference restated here: interpolate.f90:1-45 (Interpolate), pbc_mod.f90:29-52
 // (MinimumImage), global_mod.f90:19-72 (GreenFunction), system_mod.f90:213-252
