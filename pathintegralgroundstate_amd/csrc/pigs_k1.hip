@@ -505,7 +505,7 @@ __device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const
                                            const int32_t *__restrict__ walker, const int32_t *__restrict__ ipv,
                                            const int32_t *__restrict__ ibv, const double *__restrict__ xnew,
                                            const double *__restrict__ xold,
-                                           const ItemMeta<DIM> &R, PipeState<DIM> &st, int lane, double *red,
+                                           const ItemMeta<DIM> &R, PipeState<DIM> &st, int k_self, int lane, double *red,
                                            double *out, double *parts)
 {
     Acc<DIM, CLS> A;
@@ -521,7 +521,8 @@ __device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const
         if (lane == 0) kn = atomicAdd(queue, 1);
         kn = __builtin_amdgcn_readfirstlane(kn);
         st.k_nn = kn;
-        const int kq = kn < n_local ? kn : 0;                         // past the end: any valid record
+        const int kq = kn < n_local ? kn : k_self;                    // past the end: this item's own record again (its
+                                                                      // slice is in L2: the look-ahead loads cost no HBM traffic)
         st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + kq * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane);
     }
     pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
     {
         const ItemRaw r0 = pipe2_request<DIM>((int)blockIdx.x + (k_cur < n_local ? k_cur : 0) * (int)gridDim.x,
                                               walker, ipv, ibv, xnew, xold, lane);
-        st.raw_next = pipe2_request<DIM>((int)blockIdx.x + (k_nx < n_local ? k_nx : 0) * (int)gridDim.x,
+        st.raw_next = pipe2_request<DIM>((int)blockIdx.x + (k_nx < n_local ? k_nx : (k_cur < n_local ? k_cur : 0)) * (int)gridDim.x,
                                          walker, ipv, ibv, xnew, xold, lane);
         pipe2_decode<DIM>(P, paths, r0, sl, cur);
         pipe2_load<DIM>(P, cur.S, 0, lane, st.a0);
@@ -579,16 +580,16 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
             if (lane == 0) kn = atomicAdd(&next_local, 1);
             kn = __builtin_amdgcn_readfirstlane(kn);
             st.k_nn = kn;
-            st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + (kn < n_local ? kn : 0) * (int)gridDim.x,
+            st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + (kn < n_local ? kn : k_cur) * (int)gridDim.x,
                                            walker, ipv, ibv, xnew, xold, lane);
             pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
             pipe2_load<DIM>(P, Snext, 1, lane, st.a1);
         } else {
             const bool odd  = (cur.b & 1) != 0;
             const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
-            if (odd)       pipe2_item<DIM, CLS_ODD>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
-            else if (endb) pipe2_item<DIM, CLS_END>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
-            else           pipe2_item<DIM, CLS_EVEN>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, lane, red, o, q);
+            if (odd)       pipe2_item<DIM, CLS_ODD>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, k_cur, lane, red, o, q);
+            else if (endb) pipe2_item<DIM, CLS_END>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, k_cur, lane, red, o, q);
+            else           pipe2_item<DIM, CLS_EVEN>(P, VT, WF, paths, sl, n_local, &next_local, walker, ipv, ibv, xnew, xold, cur, st, k_cur, lane, red, o, q);
         }
         pipe2_decode<DIM>(P, paths, st.raw_next, sl, cur);       // arrived long ago: readlanes only
         k_cur = k_nx;
