@@ -496,6 +496,8 @@ struct PipeState {
     ItemRaw raw_next;         // the next item's record (requested one item ago; decoded when its turn comes)
     ItemRaw raw_nn;           // record of the item after it (requested mid-item)
     int k_nn;                 // queue index of that item
+    bool has_next;            // the wave has a next item
+    const double *idle;       // what the look-ahead reads when it has not
     double a0[DIM], a1[DIM];  // passes 0/1: of the current item on entry, of the next item on exit
 };
 
@@ -515,7 +517,9 @@ __device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const
     pipe2_load<DIM>(P, R.S, 3, lane, b1);
     pipe2_pass<DIM, CLS, 1>(P, VT, WF, R, st.a1, lane, A);
     // the next item's record arrived an item ago; the one after it is drawn from the queue and requested now
-    const double *Snext = pipe2_slice<DIM>(P, paths, st.raw_next, sl);
+    // no next item: the look-ahead loads still run (a branch here costs 40 spilled VGPRs) but read `idle`, a
+    // region every CU keeps hot in L2 (the table in global memory): no HBM traffic for nothing
+    const double *Snext = st.has_next ? pipe2_slice<DIM>(P, paths, st.raw_next, sl) : st.idle;
     {
         int kn = 0;
         if (lane == 0) kn = atomicAdd(queue, 1);
@@ -568,14 +572,16 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
     double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
     __syncthreads();                                            // the only workgroup barrier
 
+    st.idle = (size_t)(P.Nmax + 2) >= sl ? VTg : paths;         // any readable region of at least one slice
     while (k_cur < n_local) {                                   // wave-uniform
+        st.has_next = k_nx < n_local;
         const int it = (int)blockIdx.x + k_cur * (int)gridDim.x;
         double *o = out + it;
         double *q = nullptr;                                     // the (DeltaPot, DeltaF2, DeltaPsi) diagnostic runs on the plain grid
         if (!cur.ok) {
             // malformed item: NaN result; keep the pipeline moving without evaluating anything
             if (lane == 0) *o = __builtin_nan("");
-            const double *Snext = pipe2_slice<DIM>(P, paths, st.raw_next, sl);
+            const double *Snext = st.has_next ? pipe2_slice<DIM>(P, paths, st.raw_next, sl) : st.idle;
             int kn = 0;
             if (lane == 0) kn = atomicAdd(&next_local, 1);
             kn = __builtin_amdgcn_readfirstlane(kn);
