@@ -209,3 +209,41 @@ def test_worm_bookkeeping_entry_points(gpu_lib, oracle):
     assert np.all(c[:, 5] <= c[:, 4]) and np.all(c[:, 7] <= c[:, 6]) and np.all(c[:, 13] <= c[:, 12])
     assert np.all(c[:, 14] <= 60 * cfg.Np) and np.all(c[:, 15] <= 60 * cfg.Nstag * cfg.Np)
     ctx.close()
+
+
+def test_sampler_forms_agree_bit_for_bit(gpu_lib, oracle):
+    """The workgroup forms of K6 (12 waves + table image in LDS, 16 / 8 / 4 waves on the global image) run the same
+    arithmetic per bead and sum beads in the same order: identical worldlines, generator states and counters."""
+    cfg = _cfg("he4_worm_s1982")
+    from oracle.pyoracle import System
+    S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = 5
+    results = {}
+    for threads in (768, 1024, 512, 256):
+        ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+        ctx.sampler_init(CWorm=cfg.CWorm, swapping=True, Nobdm=cfg.Nobdm, Nbin=cfg.Nbin, Npw=0)
+        ctx.set_tuning("sweep_threads", threads)
+        Paths = []
+        for w in range(W):
+            P, g = oracle.init_path(S, 500 + w)
+            Paths.append(P)
+            ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+        Paths = np.stack(Paths)
+        ctx.upload_all(Paths)
+        xe = np.repeat(Paths[:, cfg.Nb, cfg.Np - 1][:, None, :], 2, axis=1)
+        ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe)
+        for istep in range(1, 31):
+            ctx.sampler_step(istep)
+        results[threads] = (ctx.download_all(), ctx.sampler_counters16(), [ctx.sampler_get_rng(w) for w in range(W)],
+                            ctx.sampler_get_worm(), ctx.sampler_nrho())
+        ctx.close()
+    ref = results[768]
+    for threads in (1024, 512, 256):
+        got = results[threads]
+        assert same_bits(got[0], ref[0]), threads
+        assert np.array_equal(got[1], ref[1]), threads
+        for a, b in zip(got[2], ref[2]):
+            assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), threads
+        assert np.array_equal(got[3][0], ref[3][0]) and np.array_equal(got[3][1], ref[3][1]) and same_bits(got[3][2], ref[3][2])
+        assert same_bits(got[4], ref[4]), threads
