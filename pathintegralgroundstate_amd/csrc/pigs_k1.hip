@@ -280,7 +280,6 @@ __device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt +
 // kernel, ahead of the HBM requests of the first items; completion is a vmcnt matter, so ONE `s_waitcnt vmcnt(0)`
 // before the workgroup barrier covers it (the first item needs its own loads by then anyway).  A wave issues the
 // chunk [u*blockDim + wid*64, +64) only if it starts inside the table; lanes past the end are masked off.
-constexpr int kTabU = 5;
 
 __device__ __forceinline__ void pipe_table_dma_issue(unsigned char *smem, const double *__restrict__ VTg, int nt, int wid, int lane)
 {
