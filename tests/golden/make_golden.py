@@ -30,7 +30,7 @@ VPI_IN = """&system
  Nblock = {Nblock}, Nstep = {Nstep}, Nbin = 100, Nk = 50
 /
 &obdm
- swapping = T, CWorm = {CWorm}, Nobdm = {Nobdm}, Npw = 0
+ swapping = T, CWorm = {CWorm}, Nobdm = {Nobdm}, Npw = {Npw}
 /
 &wavefun
  Nmax = 10000, wf_table = T, v_table = T
@@ -48,7 +48,7 @@ def run_vpi(workdir, **kw):
     """Run the stock reference program; returns the checkpointed worldline (M,Np,dim)."""
     p = dict(dim=3, Np=64, density="0.365d0", trap="F", dt="5.0d-3", Nb=40, seed=1982,
              sampling="bis", Lstag=16, Nlev=4, Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0",
-             Nobdm=0, a_ho="1.0d0")
+             Nobdm=0, Npw=0, a_ho="1.0d0")
     p.update(kw)
     with open(os.path.join(workdir, "vpi.in"), "w") as f:
         f.write(VPI_IN.format(**p))
@@ -182,21 +182,29 @@ def ref_gf(ref, S, opt, ib):
     return ref.green_function(opt, ib, 5e-3, 1.2345678901234, -9.87654321)
 
 
-if __name__ == "__main__":
-    main()
 
 
 # ---------------------------------------------------------------------------------------------
 # End-to-end runs of the stock reference PROGRAM (oracle/_ref/vpi): its output files are kept
 # as data fixtures under tests/golden/vpi_runs/<name>/ for the front-end / sampler tests.
+# Next to them driver.npz: the same run through tests/golden/ref_driver.py (the reference's own
+# movers and estimators called in the program's schedule, validated here against the program:
+# bit-identical final worldline) with 64-bit block energies, per-step energies, final generator
+# state, counters and event log.  Runs with `potential` other than aziz2 exist only in driver form:
+# the reference compiles ONE pair potential in, the table of another is fed in at the table boundary.
 RUNS = {
-    # worm sector active: open / close / swap / OBDM, bisection sampling
+    # worm sector active: open / close / swap / OBDM with partial waves (Npw = 1), bisection sampling
     "he4_worm_s1982": dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
                            Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
     "he4_worm_s1983": dict(dim=3, Np=16, Nb=8, seed=1983, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
                            Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
     "he4_worm_s1984": dict(dim=3, Np=16, Nb=8, seed=1984, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
                            Nblock=6, Nstep=25, CWorm="0.5d0", Nobdm=4, Npw=1),
+    # a busier worm (dt = 0.02, CWorm = 0.6): several opens, closes and dozens of accepted swaps; Npw = 2
+    "he4_wormbusy_s7": dict(dim=3, Np=16, Nb=8, seed=7, dt="2.0d-2", sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                            Nblock=6, Nstep=20, CWorm="0.6d0", Nobdm=4, Npw=2),
+    "he4_wormbusy_s8": dict(dim=3, Np=16, Nb=8, seed=8, dt="2.0d-2", sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                            Nblock=6, Nstep=20, CWorm="0.6d0", Nobdm=4, Npw=2),
     # BASELINE config 1: 1D harmonic oscillator, N=2, 21 beads, staging sampling (swapping=T: quirk Q9)
     "ho1d_n2": dict(dim=1, Np=2, Nb=10, seed=1982, trap="T", a_ho="1.0d0", sampling="sta", Lstag=6, Nlev=2,
                     Nstag=4, Nblock=5, Nstep=40, CWorm="0.3d0", Nobdm=2, Npw=0, dt="1.0d-2"),
@@ -213,28 +221,100 @@ RUNS = {
     # CWorm = 0 (quirk Q11): an open proposal is generated and always rejected
     "he4_cworm0": dict(dim=2, Np=9, Nb=6, seed=7, density="0.25d0", sampling="sta", Lstag=4, Nlev=2, Nstag=2,
                        Nblock=3, Nstep=20, CWorm="0.0d0", Nobdm=0, Npw=0),
+    # ---- BASELINE sizes ------------------------------------------------------------------------
+    # C3: liquid 4He N=256, 161 beads, stock schedule, CWorm = 0
+    "c3_n256_s1982": dict(dim=3, Np=256, Nb=80, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                          Nblock=1, Nstep=3, CWorm="0.0d0", Nobdm=0, Npw=0, big=True),
+    "c3_n256_s1983": dict(dim=3, Np=256, Nb=80, seed=1983, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                          Nblock=1, Nstep=3, CWorm="0.0d0", Nobdm=0, Npw=0, big=True),
+    # C5: N=256, 321 beads, worm sector with swaps and partial waves.  The Aziz form is what the program runs;
+    # the dipolar form (BASELINE config 5's potential) goes through the driver with the r^-3 table.
+    # CWorm = 20: the first open attempt of so short a run (step 4 for this seed) is accepted
+    "c5_n256_aziz_s1982": dict(dim=3, Np=256, Nb=160, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                               Nblock=2, Nstep=4, CWorm="20.0d0", Nobdm=10, Npw=2, big=True),
+    "c5_n256_dipolar_s1982": dict(dim=3, Np=256, Nb=160, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                                  Nblock=2, Nstep=4, CWorm="20.0d0", Nobdm=10, Npw=2, big=True, potential="dipolar"),
 }
 RUN_FILES = ["e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out", "fort.99"]
+BIG_STRIDE = 8           # fixtures of the N=256 runs keep every 8th bead + SHA-256 + per-bead sums
 
 
-def make_runs():
+def _fnum(x):
+    return float(str(x).replace("d", "e"))
+
+
+def drive_run(ref, kw, VT=None):
+    """The run `kw` through ref_driver.drive(); returns (System, result)."""
+    import ref_driver as rd
+    trap = kw.get("trap", "F") == "T"
+    a_ho = [float(t.replace("d", "e")) for t in str(kw.get("a_ho", "1.0d0")).split()]
+    density = _fnum(kw.get("density", "0.365d0"))
+    if trap:
+        from pathintegralgroundstate_amd import SystemConfig
+        density = SystemConfig(dim=kw["dim"], Np=kw["Np"], Nb=kw["Nb"], trap=True, a_ho=a_ho).density   # vpi.f90:82-93
+    S = System(dim=kw["dim"], Np=kw["Np"], Nb=kw["Nb"], density=density,
+               dt=_fnum(kw.get("dt", "5.0d-3")), trap=trap, a_ho=a_ho if trap else None,
+               CWorm=_fnum(kw["CWorm"]), Npw=kw["Npw"], Nbin=100)
+    VTr, WF = ref.tables(S)
+    if VT is None:
+        VT = VTr
+    res = rd.drive(ref, S, VT, WF, kw["seed"], Nblock=kw["Nblock"], Nstep=kw["Nstep"], sampling=kw["sampling"],
+                   Lstag=kw["Lstag"], Nlev=kw["Nlev"], Nstag=kw["Nstag"], CMFreq=1, delta_cm=0.12,
+                   CWorm=_fnum(kw["CWorm"]), Nobdm=kw["Nobdm"], swapping=True, Nk=50)
+    return S, res
+
+
+def make_runs(only=None):
     import shutil
+    import ref_driver as rd
+    from pathintegralgroundstate_amd import SystemConfig, api
+    ref = Ref()
     base = os.path.join(OUT, "vpi_runs")
     for name, kw in RUNS.items():
+        if only and name not in only:
+            continue
+        kw = dict(kw)
+        big = kw.pop("big", False)
+        potential = kw.pop("potential", "aziz2")
         dst = os.path.join(base, name)
         os.makedirs(dst, exist_ok=True)
+        P = None
         with tempfile.TemporaryDirectory() as td:
-            P = run_vpi(td, **kw)
+            if potential == "aziz2":
+                P = run_vpi(td, **kw)
+                for f in RUN_FILES:
+                    if os.path.exists(os.path.join(td, f)):
+                        shutil.copy(os.path.join(td, f), os.path.join(dst, f))
+            else:
+                p = dict(dim=3, Np=64, density="0.365d0", trap="F", dt="5.0d-3", Nb=40, seed=1982, sampling="bis",
+                         Lstag=16, Nlev=4, Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, a_ho="1.0d0")
+                p.update(kw)
+                with open(os.path.join(td, "vpi.in"), "w") as f:
+                    f.write(VPI_IN.format(**p))
             shutil.copy(os.path.join(td, "vpi.in"), os.path.join(dst, "vpi.in"))
-            for f in RUN_FILES:
-                if os.path.exists(os.path.join(td, f)):
-                    shutil.copy(os.path.join(td, f), os.path.join(dst, f))
-            np.savez_compressed(os.path.join(dst, "final_worldline.npz"), Path=P)
+        VT = None
+        if potential != "aziz2":
+            # the table of a potential the reference does not compile in: filled by the product's own host-side
+            # table builder (pigs_tables.cpp) -- input data for both sides of the comparison
+            cfg = SystemConfig.from_namelists(open(os.path.join(dst, "vpi.in")).read())
+            VT, _ = api.build_tables(cfg, potential)
+        S, res = drive_run(ref, kw, VT)
+        if P is not None:
+            rd.validate_against_program(res, P, np.loadtxt(os.path.join(dst, "e_vpi.out")).reshape(-1, 4)
+                                        if os.path.getsize(os.path.join(dst, "e_vpi.out")) else np.zeros((0, 4)),
+                                        np.loadtxt(os.path.join(dst, "et_vpi.out")).reshape(-1, 4)
+                                        if os.path.getsize(os.path.join(dst, "et_vpi.out")) else np.zeros((0, 4)))
+        c = rd.compact(res, BIG_STRIDE if big else 1)
+        if not big:
+            np.savez_compressed(os.path.join(dst, "final_worldline.npz"), Path=res["Path"])
+            del c["Path_sub"]
+        elif os.path.exists(os.path.join(dst, "final_worldline.npz")):
+            os.remove(os.path.join(dst, "final_worldline.npz"))
+        c["potential"] = np.array(potential)
+        np.savez_compressed(os.path.join(dst, "driver.npz"), **c)
+        print(name, "counters", dict(zip(rd.COUNTER_NAMES, res["counters"].tolist())), "events", len(res["events"]),
+              flush=True)
     print("reference program runs written to", base)
-
-
-if __name__ == "__main__":
-    make_runs()
 
 
 def make_resume_fixture():
@@ -266,8 +346,22 @@ def make_resume_fixture():
         for f in RUN_FILES:
             if os.path.exists(os.path.join(td, f)):
                 shutil.copy(os.path.join(td, f), os.path.join(dst, f))
+        # the worldline the resumed run ends on (its checkpoint.dat), as a fixture of its own
+        dim, Np, M = 3, 16, 17
+        with open(os.path.join(td, "checkpoint.dat")) as f:
+            lines = f.read().split("\n")
+        vals = np.array([[float(x) for x in ln.split()] for ln in lines[3:3 + Np * M]])
+        np.savez_compressed(os.path.join(dst, "final_worldline.npz"),
+                            Path=np.ascontiguousarray(vals.reshape(Np, M, dim).transpose(1, 0, 2)))
     print("resume fixture written to", dst)
 
 
 if __name__ == "__main__":
-    make_resume_fixture()
+    sys.path.insert(0, OUT)
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "vectors"):
+        main()
+    if what in ("all", "runs"):
+        make_runs(set(sys.argv[2:]) or None)
+    if what in ("all", "resume"):
+        make_resume_fixture()

@@ -50,3 +50,58 @@ def same_bits(a, b):
     a, b = np.ascontiguousarray(a, float), np.ascontiguousarray(b, float)
     return np.array_equal(a.view(np.uint64), b.view(np.uint64)) or \
         bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+# ---- fixtures written by tests/golden/ref_driver.py (driver.npz next to a reference-program run) ----
+def fold_maxnorm(d, Lbox, trap=False):
+    """max |d| after folding every coordinate difference by the box length (a last-bit difference may sit on
+    either side of the wrap at +-L/2)."""
+    d = np.asarray(d, float)
+    if not trap:
+        L = np.asarray(Lbox[:d.shape[-1]], float)
+        d = d - L * np.round(d / L)
+    return float(np.max(np.abs(d))) if d.size else 0.0
+
+
+def read_hex_blocks(path):
+    """e_vpi.hex of pigs_vpi: one line per diagonal block = block number + E K V Et Kt Vt (per particle) as
+    64-bit hex -> (blocks int array, (n,6) float array)."""
+    import struct
+    blocks, rows = [], []
+    for ln in open(path):
+        t = ln.split()
+        if not t:
+            continue
+        blocks.append(int(t[0]))
+        rows.append([struct.unpack(">d", bytes.fromhex(h))[0] for h in t[1:7]])
+    return np.array(blocks, int), np.array(rows, float).reshape(-1, 6)
+
+
+def driver_blocks(drv):
+    """(blocks, (n,6)) of a driver.npz in the e_vpi.hex column order: E K V Et Kt Vt."""
+    be, bt = drv["block_e"], drv["block_t"]
+    return be[:, 0].astype(int), np.concatenate([be[:, 1:4], bt[:, 1:4]], axis=1)
+
+
+def sha256_of(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, float).tobytes()).digest(), np.uint8)
+
+
+def check_worldline_vs_driver(P, drv, Lbox, trap=False, tol=0.0):
+    """A final worldline (M,Np,dim) against a driver.npz: tol = 0 asks for identical bits (SHA-256 of the whole
+    array), tol > 0 for the L-folded max-norm on the stored beads and on every bead's coordinate sums."""
+    P = np.ascontiguousarray(P, float)
+    assert tuple(P.shape) == tuple(int(x) for x in drv["Path_shape"]), (P.shape, drv["Path_shape"])
+    if tol == 0.0:
+        assert np.array_equal(sha256_of(P), drv["Path_sha256"]), "final worldline differs from the reference's (a decision flipped)"
+        return 0.0
+    worst = 0.0
+    if "Path_sub" in drv:
+        st = int(drv["bead_stride"])
+        worst = fold_maxnorm(P[::st] - drv["Path_sub"], Lbox, trap)
+        assert worst < tol, worst
+    # every bead enters through its coordinate sums (folded by L: wraps shift a sum by multiples of L)
+    s = fold_maxnorm(P.sum(axis=1) - drv["bead_sums"], Lbox, trap)
+    assert s < tol * P.shape[1], s
+    return max(worst, s / P.shape[1])

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from helpers import same_bits
+from helpers import check_worldline_vs_driver, driver_blocks, read_hex_blocks, same_bits
 from hostlib import build_cpu_host
 
 RUNS = os.path.join(GOLDEN, "vpi_runs")
@@ -37,8 +37,10 @@ def exe():
     return build_cpu_host()[2]
 
 
-@pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0"])
+@pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0",
+                                  "he4_wormbusy_s7", "he4_wormbusy_s8"])
 def test_front_end_reproduces_reference_files(exe, name, tmp_path):
+    """he4_wormbusy_*: Npw = 2 partial waves in nr_vpi.out and dozens of accepted swaps (fort.99)."""
     src = os.path.join(RUNS, name)
     run_pigs_vpi(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))
     for f in FILES:
@@ -48,6 +50,36 @@ def test_front_end_reproduces_reference_files(exe, name, tmp_path):
     assert same_bits(final_worldline(str(tmp_path), want.shape)[0], want)
     ref_perm = open(os.path.join(src, "fort.99")).read().split()
     assert open(tmp_path / "perm_vpi.out").read().split() == ref_perm
+    # block energies beyond the 10 printed digits: e_vpi.hex against the reference's own estimators evaluated
+    # in the program's schedule (driver.npz, tests/golden/ref_driver.py)
+    drv = dict(np.load(os.path.join(src, "driver.npz")))
+    blocks, rows = read_hex_blocks(tmp_path / "e_vpi.hex")
+    wb, wrows = driver_blocks(drv)
+    assert np.array_equal(blocks, wb)
+    assert np.all(np.abs(rows - wrows) <= 1e-13 * np.abs(wrows)), np.max(np.abs(rows - wrows) / np.abs(wrows))
+
+
+@pytest.mark.parametrize("name", ["c3_n256_s1982", "c5_n256_dipolar_s1982"])
+def test_front_end_at_baseline_sizes(exe, name, tmp_path):
+    """BASELINE configs 3 and 5 (N=256, 161 / 321 beads; C5 with the dipolar table, worm sector and swaps) through
+    the host-driven sampler: final worldline bit-identical to the reference's movers run in the program's
+    schedule (SHA-256 of all N*M*3 coordinates), 64-bit block energies, and -- where the reference PROGRAM can run
+    the input (Aziz potential) -- its files byte for byte."""
+    src = os.path.join(RUNS, name)
+    drv = dict(np.load(os.path.join(src, "driver.npz")))
+    pot = str(drv["potential"])
+    run_pigs_vpi(exe, open(os.path.join(src, "vpi.in")).read() +
+                 f"&gpu\n n_walkers = 1, device = 0, potential = '{pot}', checkpointing = F\n/\n", str(tmp_path))
+    shape = tuple(int(x) for x in drv["Path_shape"])
+    got = final_worldline(str(tmp_path), shape)[0]
+    check_worldline_vs_driver(got, drv, None, tol=0.0)
+    blocks, rows = read_hex_blocks(tmp_path / "e_vpi.hex")
+    wb, wrows = driver_blocks(drv)
+    assert np.array_equal(blocks, wb)
+    assert np.all(np.abs(rows - wrows) <= 1e-13 * np.abs(wrows)), np.max(np.abs(rows - wrows) / np.abs(wrows))
+    for f in FILES:
+        if os.path.exists(os.path.join(src, f)):
+            assert open(os.path.join(src, f), "rb").read() == open(tmp_path / f, "rb").read(), f
 
 
 def test_lockstep_walkers_reproduce_per_seed_reference_runs(exe, tmp_path):
