@@ -4,8 +4,9 @@ Two libraries:
   * ``Oracle`` : oracle/libpigs_oracle.so, our scalar C restatement (pigs_oracle.c).
   * ``Ref``    : oracle/_ref/libvpiref.so, the unmodified reference Fortran compiled by
                  oracle/Makefile plus our bind(C) probe (ref_probe.f90).  Exists only
-                 where it was built (this container; it travels to the GPU box as a
-                 prebuilt file).  ``Ref.available()`` says whether it is there.
+                 where it was built (the build container: .gpurunignore keeps it off the
+                 GPU box -- the fixtures it generated travel instead).  ``Ref.available()``
+                 says whether it is there.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
 Array conventions are the reference's: Fortran column-major, ip 1-based, ib 0-based.
