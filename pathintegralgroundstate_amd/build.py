@@ -13,8 +13,9 @@ SOURCES = ["pigs_k1.hip", "pigs_sampler.hip", "pigs_kernels.hip", "pigs_capi.hip
 HEADERS = ["pigs_device.h", "pigs_k1_device.h", "pigs_kernels.h", "pigs_comm.h"]
 # -ffp-contract=off: every per-pair term must round exactly like the reference's x86-64
 # build (no FMA); hipcc's default is fast contraction.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
+OBJDIR = os.environ.get("PIGS_OBJDIR", "/tmp/pigs_hip_obj")
 
 
 def hipcc():
@@ -34,13 +35,36 @@ def stale():
 
 
 def build(force=False, verbose=False):
+    """One object per source, compiled in parallel (the sampler and K1 dominate), then one link.  Objects live
+    in a scratch directory keyed by the flags; `force` recompiles everything."""
     if not force and not stale():
         return LIB
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("PIGS_EXTRA_FLAGS", "").split()          # experiment builds (e.g. -DPIGS_SWEEP_TIMING)
-    cmd = [hipcc()] + FLAGS + extra + ["-I" + os.path.join(ROOT, "include")] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
+    cc = hipcc()
+    inc = "-I" + os.path.join(ROOT, "include")
+    odir = os.path.join(OBJDIR, hashlib.sha1(" ".join(FLAGS + extra + [CSRC]).encode()).hexdigest()[:12])
+    os.makedirs(odir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(p) for p in [os.path.join(CSRC, h) for h in HEADERS] +
+                [os.path.join(ROOT, "include", "pigs_hip.h")])
+
+    def compile_one(src):
+        obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            return obj
+        cmd = [cc] + FLAGS + extra + [inc, "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

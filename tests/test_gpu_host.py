@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
-from helpers import check_worldline_vs_driver, driver_blocks, fold_maxnorm, read_hex_blocks, same_bits
+from helpers import (MIXED_TOL_NOT_BIT_IDENTICAL, block_energy_errors, check_worldline_vs_driver, driver_blocks,
+                     fold_maxnorm, read_hex_blocks, same_bits)
 from pathintegralgroundstate_amd import SystemConfig
 
 pytestmark = pytest.mark.gpu
@@ -43,15 +44,18 @@ def _close(mine, ref, rel=1e-10):
     return np.all(np.abs(a - b) <= rel * np.abs(b) + 1.01e-9 * np.abs(b))
 
 
-def _hex_close(hexfile, src, rel=1e-10):
+def _hex_close(hexfile, src, rel=1e-10, mixed=1e-10):
     """Block energies E K V Et Kt Vt (per particle) of e_vpi*.hex against the 64-bit values of the reference's own
-    estimators run in the program's schedule (driver.npz): 1e-10 relative, no printing floor."""
+    estimators run in the program's schedule (driver.npz): 1e-10 relative (helpers.block_energy_errors), no printing
+    floor.  `mixed` is the bound for the E, K columns: 1e-10 where the worldline is bit-identical (host-driven
+    sampler), helpers.MIXED_TOL_NOT_BIT_IDENTICAL for the device-resident sampler (see there)."""
     drv = dict(np.load(os.path.join(src, "driver.npz")))
     blocks, rows = read_hex_blocks(hexfile)
     wb, wrows = driver_blocks(drv)
     assert np.array_equal(blocks, wb), (blocks, wb)
-    err = np.abs(rows - wrows) / np.abs(wrows)
-    assert np.all(err <= rel), err.max()
+    em, er = block_energy_errors(rows, wrows)
+    assert np.all(er <= rel), er.max()
+    assert np.all(em <= mixed), em.max()
     return True
 
 
@@ -121,7 +125,7 @@ def test_gpu_front_end_device_sampler_at_baseline_sizes(exe, name, tmp_path):
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(shape)
     Lbox, trap = _lbox(src)
     check_worldline_vs_driver(got, drv, Lbox, trap, tol=1e-10)
-    assert _hex_close(tmp_path / "e_vpi.hex", src)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
     if os.path.exists(os.path.join(src, "nr_vpi.out")):
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     if os.path.exists(os.path.join(src, "gr_vpi.out")):
@@ -152,7 +156,7 @@ def test_gpu_front_end_with_device_resident_sampler(exe, tmp_path):
         want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
         d = got.reshape((2,) + want.shape)[w] - want
         assert fold_maxnorm(d, *_lbox(src)) < 1e-10
-        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src)
+        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
         assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
         assert _close(tmp_path / f"sk_vpi.w{w:04d}.out", os.path.join(src, "sk_vpi.out"), rel=1e-8)
 
@@ -169,7 +173,7 @@ def test_gpu_front_end_device_sampler_worm_sector(exe, tmp_path):
         want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
         d = got.reshape((3,) + want.shape)[w] - want
         assert fold_maxnorm(d, *_lbox(src)) < 1e-10, w
-        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src)
+        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
         assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / f"nr_vpi.w{w:04d}.out", "rb").read(), w
         assert open(tmp_path / f"perm_vpi.w{w:04d}.out").read().split() == open(os.path.join(src, "fort.99")).read().split(), w
@@ -186,7 +190,7 @@ def test_gpu_front_end_device_sampler_stock_input(exe, tmp_path):
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
     assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
-    assert _hex_close(tmp_path / "e_vpi.hex", src)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
 
@@ -202,7 +206,7 @@ def test_gpu_front_end_device_sampler_staging_movers(exe, name, tmp_path):
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
     assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
-    assert _hex_close(tmp_path / "e_vpi.hex", src)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
     if os.path.exists(os.path.join(src, "nr_vpi.out")):
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
@@ -265,7 +269,8 @@ def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, 
     for w in range(3):
         ba, ra = read_hex_blocks(a / f"e_vpi.w{w:04d}.hex")
         bb, rb = read_hex_blocks(b / f"e_vpi.w{w:04d}.hex")
-        assert np.array_equal(ba, bb) and np.all(np.abs(ra - rb) <= 1e-10 * np.abs(ra)), w
+        em, er = block_energy_errors(rb, ra)
+        assert np.array_equal(ba, bb) and np.all(er <= 1e-10) and np.all(em <= MIXED_TOL_NOT_BIT_IDENTICAL), w
         assert open(a / f"nr_vpi.w{w:04d}.out", "rb").read() == open(b / f"nr_vpi.w{w:04d}.out", "rb").read(), w
         assert open(a / f"perm_vpi.w{w:04d}.out").read() == open(b / f"perm_vpi.w{w:04d}.out").read(), w
 

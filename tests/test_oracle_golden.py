@@ -108,3 +108,31 @@ def test_rng_bit_exact(oracle):
     gs = np.array([oracle.rangauss(g, 1.0, 0.0) for _ in range(len(r["rangauss"]))])
     assert same_bits(gs, r["rangauss"])
     assert g.mti == int(r["mti_after_gauss"]) and np.array_equal(np.array(g.mt[:], np.uint32), r["mt_after_gauss"])
+
+
+def test_mixed_estimator_is_ill_conditioned_at_one_ulp(oracle):
+    """Why helpers.MIXED_TOL_NOT_BIT_IDENTICAL exists.  LocalEnergy takes d2u/dr2 as a second difference of the
+    linear interpolant divided by dr^2 (interpolate.f90:36-42) with dr = rcut/9999: rounding is amplified by ~1e7.
+    Moving every coordinate of a slice by ONE ulp moves the reference's own E and Kin by several 1e-10 of
+    |K|+|V| on the worm-busy run's worldline (6e-11 on the equilibrated N=64 one; Pot stays at 1e-14), so a sampler
+    whose coordinates differ from the reference's in the last bit (the device-resident one: device log() in
+    Box-Muller) cannot match the mixed estimator to 1e-10 step by step, whatever it computes; one whose worldline is
+    bit-identical (the host-driven one) does."""
+    import os
+    from conftest import GOLDEN
+    from helpers import MIXED_TOL_NOT_BIT_IDENTICAL
+    from oracle.pyoracle import System
+    S = System(dim=3, Np=16, Nb=8, density=0.365, dt=2e-2)
+    VT, WF = oracle.tables(S)
+    P = np.load(os.path.join(GOLDEN, "vpi_runs", "he4_wormbusy_s7", "final_worldline.npz"))["Path"]
+    rng = np.random.default_rng(3)
+    worst = np.zeros(3)
+    for ib in (0, 2 * S.Nb):
+        R = P[ib]
+        e0 = np.array(oracle.local_energy(S, WF, VT, R))
+        scale = abs(e0[1]) + abs(e0[2])
+        for _ in range(100):
+            R2 = np.nextafter(R, R + rng.choice([-1.0, 1.0], R.shape))
+            worst = np.maximum(worst, np.abs(np.array(oracle.local_energy(S, WF, VT, R2)) - e0) / scale)
+    assert worst[2] < 1e-13                                   # the potential energy is well conditioned
+    assert 1e-10 < worst[0] < MIXED_TOL_NOT_BIT_IDENTICAL and 1e-10 < worst[1] < MIXED_TOL_NOT_BIT_IDENTICAL, worst
