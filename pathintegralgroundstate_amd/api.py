@@ -67,6 +67,7 @@ def load_library(path=LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("PIGS_LIB", path)           # experiment builds (scripts/: e.g. the -DPIGS_SWEEP_TIMING library)
     if not os.path.exists(path):
         raise PigsError(
             f"{path} is missing: build it with `python -m pathintegralgroundstate_amd.build` "

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpigs_hip.so")
-SOURCES = ["pigs_k1.hip", "pigs_sampler.hip", "pigs_kernels.hip", "pigs_capi.hip", "pigs_comm.cpp", "pigs_tables.cpp"]
-HEADERS = ["pigs_device.h", "pigs_k1_device.h", "pigs_kernels.h", "pigs_comm.h"]
+SOURCES = ["pigs_k1.hip", "pigs_sampler.hip", "pigs_diag.hip", "pigs_kernels.hip", "pigs_capi.hip", "pigs_comm.cpp", "pigs_tables.cpp"]
+HEADERS = ["pigs_device.h", "pigs_k1_device.h", "pigs_kernels.h", "pigs_comm.h", "pigs_sampler_device.h"]
 # -ffp-contract=off: every per-pair term must round exactly like the reference's x86-64
 # build (no FMA); hipcc's default is fast contraction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
@@ -37,7 +37,7 @@ def stale():
 def build(force=False, verbose=False):
     """One object per source, compiled in parallel (the sampler and K1 dominate), then one link.  Objects live
     in a scratch directory keyed by the flags; `force` recompiles everything."""
-    if not force and not stale():
+    if not force and not stale() and not os.environ.get("PIGS_LIB_OUT"):
         return LIB
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
@@ -62,11 +62,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
+    lib = os.environ.get("PIGS_LIB_OUT", LIB)          # experiment builds go next to the product library
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

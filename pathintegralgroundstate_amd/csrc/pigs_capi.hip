@@ -106,6 +106,8 @@ struct pigs_ctx {
     SweepParams sweep{};
     int         cm_freq = 1;
     int         sweep_threads = 512;
+    bool        sweep_split = false;    // diagonal moves of periodic 'bis' systems in pigs_diag.hip's kernel (see pigs_sampler_step)
+    int         n_cu = 256;
     bool        sampler_ready = false;
 };
 
@@ -255,8 +257,8 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
         c->k1_variant = value;
         return PIGS_OK;
     }
-    if (!strcmp(key, "sweep_debug")) {          // bit 0: skip the Delta-S evaluation of bisection stages (timing only)
-        c->sweep.pad0 = value;
+    if (!strcmp(key, "sweep_split")) {          // 1: stage-machine kernel (pigs_diag.hip) for the diagonal bisection moves; 0 (default): one kernel
+        c->sweep_split = value != 0;
         return PIGS_OK;
     }
     if (!strcmp(key, "sweep_threads")) {
@@ -526,8 +528,12 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     if (!sp) return fail(PIGS_ERR_ARG, "null sweep params");
     const bool sta = sp->sampling == 1;
     if (sp->sampling != 0 && sp->sampling != 1) return fail(PIGS_ERR_ARG, "sampling must be 0 ('bis') or 1 ('sta')");
-    if ((!sta && (sp->Nlev < 1 || (1 << sp->Nlev) > 16 || (1 << sp->Nlev) > 2 * c->P.Nb)) || sp->Nstag < 0 || sp->CMFreq < 1 ||
-        sp->Lstag < 2 || sp->Lstag > c->P.Nb)
+    const bool worm0 = sp->CWorm > 0.0;
+    // Nlev: any 2^Nlev <= 2 Nb up to 7 levels for periodic systems (pigs_diag.hip beyond 4), 4 for trapped ones;
+    // Lstag <= Nb is a requirement of the worm's half-chain moves only (vpi_mod.f90:1376-1817): with CWorm = 0 any
+    // Lstag <= 2 Nb works, as in the reference
+    if ((!sta && (sp->Nlev < 1 || sp->Nlev > (c->P.trap ? 4 : 7) || (1 << sp->Nlev) > 2 * c->P.Nb)) || sp->Nstag < 0 || sp->CMFreq < 1 ||
+        sp->Lstag < 2 || sp->Lstag > (worm0 ? c->P.Nb : 2 * c->P.Nb))
         return fail(PIGS_ERR_ARG, "sweep params out of range (Nlev=%d Nstag=%d CMFreq=%d Lstag=%d)", sp->Nlev, sp->Nstag, sp->CMFreq, sp->Lstag);
     const bool worm = sp->CWorm > 0.0;
     if (worm && (sp->Nobdm < 0 || sp->Nbin < 1 || sp->Npw < 0 || !(sp->rbin > 0.0) || !(sp->density > 0.0)))
@@ -541,13 +547,17 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     k.Nbin = worm ? sp->Nbin : 1; k.Npw = worm ? sp->Npw : 0; k.rbin = worm ? sp->rbin : 1.0;
     k.log_cworm_density = worm ? std::log(sp->CWorm * sp->density) : 0.0;      // host libm, as the reference
     c->cm_freq = sp->CMFreq;
-    // one workgroup per walker: 16 waves when every walker gets a CU of its own, 4 waves (3 workgroups
-    // per CU) when there are more walkers than CUs (measured: scripts/sampler_bench.py)
-    // ... and 12 waves with the VTable image in LDS when that fits (periodic systems)
-    c->sweep_threads = c->n_walkers > 256 ? 256 : 1024;
-    if (c->sweep_threads == 1024 && !c->P.trap && !(c->P.Nmax & 1) && sweep_lds_bytes(c->P, c->sweep, 768) <= 160 * 1024)
-        c->sweep_threads = 768;
-    if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) c->sweep_threads = 512;
+    // one workgroup per walker: the 8-wave form (periodic: table image in LDS) while every walker gets a CU of its own,
+    // the 4-wave form (three workgroups per CU) beyond that (measured: scripts/sampler_bench.py)
+    {
+        int dev = 0, ncu = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ncu = pr.multiProcessorCount;
+        c->n_cu = ncu;
+        c->sweep_threads = sweep_form(c->P, c->sweep, c->n_walkers > ncu ? 256 : 1024);
+    }
+    if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) c->sweep_threads = sweep_form(c->P, c->sweep, 256);
     if (sweep_lds_bytes(c->P, c->sweep, c->sweep_threads) > 160 * 1024) return fail(PIGS_ERR_UNSUPPORTED, "worldline too long for the sampler's LDS staging");
     const size_t W = c->n_walkers;
     if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, W * kRngWords * sizeof(uint32_t)));
@@ -620,8 +630,29 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
     SweepParams sp = c->sweep;
     sp.do_cm = (istep % c->cm_freq) == 0;
-    HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
-                        c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+    // Two forms of the diagonal bisection moves of a periodic system: inside the one-launch kernel (pigs_sampler.hip;
+    // Nlev <= 4), or the stage machine of pigs_diag.hip between two launches of that kernel for the open / close attempt
+    // and the worm moves (any Nlev with 2^Nlev <= 2 Nb, Nlev <= 7).  Measured at N=256, 161 beads, 128 walkers: 48.1 ms
+    // vs 56.5 ms per MC step (profiles/r02_k6_stage_machine.txt), so the stage machine runs only where the other form
+    // cannot, or on request (pigs_set_tuning "sweep_split" = 1).
+    const bool need_split = !c->P.trap && !sp.staging && sp.Nlev > 4;
+    const bool split = (c->sweep_split || need_split) && diag_supported(c->P, sp);
+    if (need_split && !split) return fail(PIGS_ERR_UNSUPPORTED, "Nlev=%d needs the stage-machine kernel, which does not fit this worldline", sp.Nlev);
+    if (split) {
+        sp.parts = 1;
+        HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                            c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+        HIPCHK(launch_diag(c->P, sp, 512, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters, c->d_worm, c->stream));
+        if (sp.worm) {
+            sp.parts = 4;
+            HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                                c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+        }
+    } else {
+        sp.parts = 7;
+        HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                            c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+    }
     return PIGS_OK;
 }
 

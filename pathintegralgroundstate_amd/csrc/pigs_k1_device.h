@@ -536,4 +536,83 @@ __device__ __forceinline__ void item_pass_pipe(const DevParams &P, PipeTab VT, c
     else           item_pass_pipe_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m, xn, xo, lane, red, tot8);
 }
 
+// ---- task form for the device-resident sampler's replicated stages (pigs_sampler.hip) ----------------------
+// A task is a run of `np` 64-partner passes of one proposal bead, starting at pass m0, for the new distance
+// (sides & 1), the old one (sides & 2) or both; its wave totals go to tot8[] in the layout of item_pass_cls.
+// np, m0 and sides are wave-uniform (scalar branches); partner coordinates of up to four passes are
+// requested up front.  A side that is not evaluated leaves zeros in its columns, so item_finish_split() can
+// add the tasks of a bead column by column whatever their shape.
+template <int DIM, int CLS>
+__device__ __forceinline__ void pipe_task_cls(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                              const double *__restrict__ S, int p, int m0, int np, int sides,
+                                              const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                              double *red, double *tot8)
+{
+    constexpr int MAXP = 4;
+    Acc<DIM, CLS> A;
+    for (int mb = m0; mb < m0 + np; mb += MAXP) {                     // one trip for Np <= 256
+        const int nn = m0 + np - mb < MAXP ? m0 + np - mb : MAXP;
+        double rj[MAXP][DIM];
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            if (m < nn) {
+                const int j = (mb + m) * kWave + lane;
+                const int jj = j < P.Np ? j : 0;                      // in-bounds dummy for idle lanes
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) rj[m][k] = S[(size_t)k * P.NpPad + jj];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            if (m < nn) {
+                const int j = (mb + m) * kWave + lane;
+                const bool valid = j < P.Np && j != p;                // row p itself never enters (vpi_mod.f90:2699)
+                if (sides & 1) {
+                    double d[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) d[k] = xn[k] - rj[m][k];
+                    const double r2 = min_image_rn<DIM>(d, P);
+                    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+                }
+                if (sides & 2) {
+                    double d[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) d[k] = xo[k] - rj[m][k];
+                    const double r2 = min_image_rn<DIM>(d, P);
+                    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (CLS == CLS_ODD) {
+        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
+        const double t = wave_reduce_lds<8>(v, red, lane);
+        if (lane < 8) tot8[lane] = t;
+    } else if (CLS == CLS_END) {
+        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
+        const double t = wave_reduce_lds<4>(v, red, lane);
+        if (lane < 4) tot8[lane] = t;
+    } else {
+        const double v[2] = {A.potN, A.potO};
+        const double t = wave_reduce_lds<2>(v, red, lane);
+        if (lane < 2) tot8[lane] = t;
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ void pipe_task(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                          const double *__restrict__ S, int p, int b, int m0, int np, int sides,
+                                          const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                          double *red, double *tot8)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       pipe_task_cls<DIM, CLS_ODD>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+    else if (endb) pipe_task_cls<DIM, CLS_END>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+    else           pipe_task_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+}
+
 } // namespace pigs

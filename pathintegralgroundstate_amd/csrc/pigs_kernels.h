@@ -59,7 +59,8 @@ constexpr int kWormDoubles = 8;     // isopen, iworm, xend(:,1), xend(:,2)
 constexpr int kEvInts = 64;         // event log of one MC step
 struct SweepParams {
     int32_t Nlev, Nstag, Lstag, do_cm;
-    int32_t open_attempt, pad0, worm, swapping;   // worm: CWorm > 0 (open/close/swap sector sampled)
+    int32_t open_attempt, parts, worm, swapping;  // worm: CWorm > 0 (open/close/swap sector sampled); parts: sections of the
+                                                  // step a launch runs (1 open/close attempt, 2 diagonal moves, 4 worm moves)
     int32_t Nobdm, Nbin, Npw, staging;            // staging: sampling = 'sta' in the diagonal sector
     double  delta_cm, log_cworm_density, rbin;
 };
@@ -68,6 +69,12 @@ hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, 
                         int *evlog, double *nrho, const double *dklog, hipStream_t st);
 hipError_t launch_slice_gather(const DevParams &P, const double *paths, int ib, double *out, hipStream_t st);
 size_t sweep_lds_bytes(const DevParams &P, const SweepParams &sp, int threads);
+// pigs_diag.hip: the diagonal moves of a periodic system with sampling = 'bis' as a stage machine (one workgroup per walker)
+bool diag_supported(const DevParams &P, const SweepParams &sp);
+int diag_form(const DevParams &P, const SweepParams &sp, int threads);      // workgroup size launch_diag uses (0: does not fit)
+hipError_t launch_diag(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VTimg,
+                       const double *WF, uint32_t *rng, unsigned long long *counters, const double *worm, hipStream_t st);
+int sweep_form(const DevParams &P, const SweepParams &sp, int threads);   // workgroup size launch_sweep uses for a request
 
 hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
                                     unsigned long long *d_bad, hipStream_t st);

@@ -110,8 +110,8 @@ program pigs_vpi
   end if
   NW  = n_walkers
   pi = acos(-1.d0)
-  if (device_sampler .and. Lstag>Nb) then
-     write (0,*) 'pigs_vpi: device_sampler = T needs Lstag <= Nb; using the host-driven sampler'
+  if (device_sampler .and. Lstag>Nb .and. CWorm>0.d0) then
+     write (0,*) 'pigs_vpi: device_sampler = T with CWorm > 0 needs Lstag <= Nb (half-chain moves); using the host-driven sampler'
      device_sampler = .false.
   end if
 

@@ -28,8 +28,8 @@ def main():
         if cworm > 0:       # every walker starts closed; xend = bead Nb of the last particle, like the reference's init
             xe = np.repeat(Paths[:, cfg.Nb, cfg.Np - 1][:, None, :], 2, axis=1)
             ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe)
-        if os.environ.get('SWEEP_DEBUG'):
-            ctx.set_tuning('sweep_debug', int(os.environ['SWEEP_DEBUG']))
+        if os.environ.get('SWEEP_SPLIT'):
+            ctx.set_tuning('sweep_split', int(os.environ['SWEEP_SPLIT']))
         if os.environ.get('SWEEP_THREADS'):
             ctx.set_tuning('sweep_threads', int(os.environ['SWEEP_THREADS']))
         for w in range(W):
@@ -44,7 +44,7 @@ def main():
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
         if os.environ.get('TIMING'):     # library built with PIGS_EXTRA_FLAGS=-DPIGS_SWEEP_TIMING
             c16 = ctx.sampler_counters16()[:, 8:].mean(0) / (nsteps + 1)
-            names = ['A gen(seg,end)', 'A sync', 'B end eval', 'B end metro+sync', 'C level gen', 'C sync', 'D level eval', 'E level metro+sync']
+            names = ['ctl: finish+metropolis', 'ctl: commit+next move', 'ctl: gaussians', 'ctl: proposal+publish', 'task: descriptor', 'task: pipe_task', 'control step total', 'bis: wait for slowest']
             print('   shader-clock cycles per MC step per walker (thread 0): ' + ', '.join(f'{n} {v / 1e3:.0f}k' for n, v in zip(names, c16)), flush=True)
         if cworm > 0:
             c16 = ctx.sampler_counters16().sum(0)

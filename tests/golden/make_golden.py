@@ -221,6 +221,13 @@ RUNS = {
     # CWorm = 0 (quirk Q11): an open proposal is generated and always rejected
     "he4_cworm0": dict(dim=2, Np=9, Nb=6, seed=7, density="0.25d0", sampling="sta", Lstag=4, Nlev=2, Nstag=2,
                        Nblock=3, Nstep=20, CWorm="0.0d0", Nobdm=0, Npw=0),
+    # Lstag > Nb with CWorm = 0 (and six bisection levels): the never-accepted open proposal of quirk Q11 then indexes
+    # beads below 0 in the reference (it reads and restores whatever lies there: harmless, deterministic); only its
+    # random numbers matter.  Program files only: the driver would run the reference's OpenChain on a numpy array.
+    "lstag_gt_nb_bis6": dict(dim=3, Np=20, Nb=40, density="0.3d0", seed=77, sampling="bis", Lstag=50, Nlev=6, Nstag=2,
+                             Nblock=2, Nstep=6, CWorm="0.0d0", Nobdm=0, Npw=0, driver=False),
+    "lstag_gt_nb_sta": dict(dim=2, Np=12, Nb=10, density="0.1d0", seed=77, sampling="sta", Lstag=15, Nlev=2, Nstag=2,
+                            Nblock=2, Nstep=6, CWorm="0.0d0", Nobdm=0, Npw=0, driver=False),
     # ---- BASELINE sizes ------------------------------------------------------------------------
     # C3: liquid 4He N=256, 161 beads, stock schedule, CWorm = 0
     "c3_n256_s1982": dict(dim=3, Np=256, Nb=80, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
@@ -276,6 +283,7 @@ def make_runs(only=None):
         kw = dict(kw)
         big = kw.pop("big", False)
         potential = kw.pop("potential", "aziz2")
+        with_driver = kw.pop("driver", True)
         dst = os.path.join(base, name)
         os.makedirs(dst, exist_ok=True)
         P = None
@@ -292,6 +300,10 @@ def make_runs(only=None):
                 with open(os.path.join(td, "vpi.in"), "w") as f:
                     f.write(VPI_IN.format(**p))
             shutil.copy(os.path.join(td, "vpi.in"), os.path.join(dst, "vpi.in"))
+        if not with_driver:
+            np.savez_compressed(os.path.join(dst, "final_worldline.npz"), Path=P)
+            print(name, "program files only", flush=True)
+            continue
         VT = None
         if potential != "aziz2":
             # the table of a potential the reference does not compile in: filled by the product's own host-side

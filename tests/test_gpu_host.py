@@ -231,21 +231,26 @@ def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     assert same_bits(np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin"))
 
 
-@pytest.mark.parametrize("sampling,extra", [("bis", "dim = 2, Np = 37, density = 0.06d0"), ("sta", "dim = 3, Np = 21, density = 0.2d0")])
-def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, sampling, extra):
+@pytest.mark.parametrize("sampling,extra,samp,cworm", [
+    ("bis", "dim = 2, Np = 37, density = 0.06d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0"),
+    ("sta", "dim = 3, Np = 21, density = 0.2d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0"),
+    # beyond the one-launch kernel's four levels: 2^5, 2^6 beads per bisection segment (pigs_diag.hip's stage machine)
+    ("bis", "dim = 3, Np = 20, density = 0.3d0", "Nb = 40, Lstag = 30, Nlev = 6", "0.0d0"),
+    ("bis", "dim = 3, Np = 70, density = 0.3d0", "Nb = 20, Lstag = 8, Nlev = 5", "0.4d0")])
+def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, sampling, extra, samp, cworm):
     """No reference run exists for these shapes; the host-driven sampler (bit-identical to the reference wherever
     a fixture exists) is the yardstick: same input, three walkers, device_sampler = F and T must give the same
-    trajectories (worldlines to 1e-9), the same block energies and identical permutation / OBDM files."""
+    trajectories (worldlines to 1e-10), the same block energies and identical permutation / OBDM files."""
     inp = f"""&system
  {extra}, trap = F
 /
 &samp
- resume = F, dt = 5.0d-3, Nb = 12, seed = 77, delta_cm = 0.15d0, CMFreq = 2,
- sampling = '{sampling}', Lstag = 6, Nlev = 3, Nstag = 2,
+ resume = F, dt = 5.0d-3, {samp}, seed = 77, delta_cm = 0.15d0, CMFreq = 2,
+ sampling = '{sampling}', Nstag = 2,
  Nblock = 3, Nstep = 12, Nbin = 50, Nk = 10
 /
 &obdm
- swapping = T, CWorm = 0.4d0, Nobdm = 3, Npw = 1
+ swapping = T, CWorm = {cworm}, Nobdm = 3, Npw = 1
 /
 &wavefun
  Nmax = 4000, wf_table = T, v_table = T
@@ -295,3 +300,19 @@ def test_gpu_resume_from_reference_checkpoint(exe, dev, tmp_path):
     for f in ("e_vpi.out", "et_vpi.out"):
         assert _close(tmp_path / f, os.path.join(src, f)), f
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+
+
+@pytest.mark.parametrize("name", ["lstag_gt_nb_bis6", "lstag_gt_nb_sta"])
+def test_gpu_device_sampler_lstag_beyond_nb(exe, name, tmp_path):
+    """Lstag > Nb with CWorm = 0 (bisection with six levels / staging sampling): the reference's never-accepted open
+    proposal (quirk Q11) then reaches below bead 0 -- only its random numbers matter, and K6 consumes exactly those.
+    The host-driven sampler restates OpenChain literally and is not run here."""
+    src = os.path.join(RUNS, name)
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = T\n/\n", str(tmp_path))
+    assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
+    for f in ("e_vpi.out", "et_vpi.out"):
+        assert _close(tmp_path / f, os.path.join(src, f)), f
+    assert _close(tmp_path / "gr_vpi.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)

@@ -214,16 +214,17 @@ def test_worm_bookkeeping_entry_points(gpu_lib, oracle):
     ctx.close()
 
 
-def test_sampler_forms_agree_bit_for_bit(gpu_lib, oracle):
-    """The workgroup forms of K6 (12 waves + table image in LDS, 16 / 8 / 4 waves on the global image) run the same
-    arithmetic per bead and sum beads in the same order: identical worldlines, generator states and counters."""
+def test_sampler_forms_agree(gpu_lib, oracle):
+    """The two workgroup forms of K6 for periodic systems (8 waves + table image in LDS; 4 waves on the global image) cut a
+    stage's Delta S into different tasks, so sums differ in the last bits -- but every decision must be the same:
+    identical generator states, counters, worm flags and OBDM l=0 column, worldlines to rounding."""
     cfg = _cfg("he4_worm_s1982")
     from oracle.pyoracle import System
     S = System(dim=cfg.dim, Np=cfg.Np, Nb=cfg.Nb, density=cfg.density, dt=cfg.dt)
     VT, WF = gpu_lib.build_tables(cfg)
     W = 5
     results = {}
-    for threads in (768, 1024, 512, 256):
+    for threads in (512, 256):
         ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
         ctx.sampler_init(CWorm=cfg.CWorm, swapping=True, Nobdm=cfg.Nobdm, Nbin=cfg.Nbin, Npw=0)
         ctx.set_tuning("sweep_threads", threads)
@@ -241,15 +242,16 @@ def test_sampler_forms_agree_bit_for_bit(gpu_lib, oracle):
         results[threads] = (ctx.download_all(), ctx.sampler_counters16(), [ctx.sampler_get_rng(w) for w in range(W)],
                             ctx.sampler_get_worm(), ctx.sampler_nrho())
         ctx.close()
-    ref = results[768]
-    for threads in (1024, 512, 256):
-        got = results[threads]
-        assert same_bits(got[0], ref[0]), threads
-        assert np.array_equal(got[1], ref[1]), threads
-        for a, b in zip(got[2], ref[2]):
-            assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), threads
-        assert np.array_equal(got[3][0], ref[3][0]) and np.array_equal(got[3][1], ref[3][1]) and same_bits(got[3][2], ref[3][2])
-        assert same_bits(got[4], ref[4]), threads
+    ref, got = results[512], results[256]
+    L = np.asarray(cfg.Lbox[:cfg.dim])
+    d = got[0] - ref[0]
+    assert np.max(np.abs(d - L * np.round(d / L))) < 1e-10
+    assert np.array_equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1]))
+    assert np.array_equal(got[3][0], ref[3][0]) and np.array_equal(got[3][1], ref[3][1])
+    assert np.max(np.abs(got[3][2] - ref[3][2])) < 1e-10
+    assert np.array_equal(got[4][:, :, 0], ref[4][:, :, 0])
 
 
 def _untemper(y):

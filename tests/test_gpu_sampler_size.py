@@ -4,8 +4,9 @@ runs it, and the dipolar r^-3 table fed in at the table boundary) -- against the
 estimators run in the program's schedule (tests/golden/vpi_runs/c3_* / c5_*: driver.npz written by
 tests/golden/ref_driver.py, which is itself checked bit for bit against the reference PROGRAM).
 
-At N=256 the kernel runs what no N<=64 fixture reaches: four 64-partner passes per bead, the four-wave split of the lone
-end bead, the 12-wave form with the table image in LDS next to 321-bead proposal buffers.
+At N=256 the kernels run what no N<=64 fixture reaches: four 64-partner passes per bead, the four-wave split of the lone
+end bead, the table image in LDS next to 321-bead proposal buffers; both forms of the diagonal bisection moves are run
+(inside the one-launch kernel, and the stage machine of pigs_diag.hip).
 
 What must hold, walker by walker: the generator ends in the reference's state word for word (every random number was
 consumed at the same place), the 16 attempt / accept counters and the event log (open / close / swap accepted, in
@@ -30,7 +31,7 @@ def _cfg(name):
     return SystemConfig.from_namelists(open(os.path.join(RUNS, name, "vpi.in")).read())
 
 
-def run_k6(gpu_lib, oracle, names, threads=None):
+def run_k6(gpu_lib, oracle, names, threads=None, split=0):
     """The reference's block loop (vpi.f90:244-545) around pigs_sampler_step for the runs `names` (same input, one
     walker per seed).  Returns per walker: per-step rows [diag, E, Kin, Pot, Et, Kt], final worldline, counters16,
     generator state, worm state, events, OBDM histogram."""
@@ -47,6 +48,7 @@ def run_k6(gpu_lib, oracle, names, threads=None):
                      sampling=cfg.sampling)
     if threads:
         ctx.set_tuning("sweep_threads", threads)
+    ctx.set_tuning("sweep_split", split)          # 1: the diagonal bisection moves in pigs_diag.hip's stage machine
     Paths, xends = [], []
     for w, n in enumerate(names):
         P, g = oracle.init_path(S, _cfg(n).seed)
@@ -124,20 +126,20 @@ def check_against_driver(r, w):
     return worst, rel.max() if d.any() else 0.0
 
 
-@pytest.mark.parametrize("threads", [None, 256])
-def test_k6_config3_n256_161_beads(gpu_lib, oracle, threads):
-    """Two walkers = the reference chains of seeds 1982 and 1983; default form (12 waves, table image in LDS) and the
-    4-wave form used beyond 256 walkers."""
-    r = run_k6(gpu_lib, oracle, ["c3_n256_s1982", "c3_n256_s1983"], threads)
+@pytest.mark.parametrize("threads,split", [(None, 0), (256, 0), (None, 1)])
+def test_k6_config3_n256_161_beads(gpu_lib, oracle, threads, split):
+    """Two walkers = the reference chains of seeds 1982 and 1983; default form (8 waves, table image in LDS), the
+    4-wave form used beyond one walker per CU, and the stage-machine kernel (pigs_diag.hip)."""
+    r = run_k6(gpu_lib, oracle, ["c3_n256_s1982", "c3_n256_s1983"], threads, split)
     for w in range(2):
         worst, rel = check_against_driver(r, w)
         print(f"walker {w}: worldline max |d| = {worst:.2e}, step energies max rel = {rel:.2e}")
 
 
 @pytest.mark.parametrize("name", ["c5_n256_aziz_s1982", "c5_n256_dipolar_s1982"])
-@pytest.mark.parametrize("threads", [None, 256])
-def test_k6_config5_n256_321_beads_worm_sector(gpu_lib, oracle, name, threads):
-    r = run_k6(gpu_lib, oracle, [name], threads)
+@pytest.mark.parametrize("threads,split", [(None, 0), (256, 0), (None, 1)])
+def test_k6_config5_n256_321_beads_worm_sector(gpu_lib, oracle, name, threads, split):
+    r = run_k6(gpu_lib, oracle, [name], threads, split)
     assert r["drv"][0]["counters"][5] >= 1                  # the worm did open in the reference run
     worst, rel = check_against_driver(r, 0)
     print(f"{name}: worldline max |d| = {worst:.2e}, step energies max rel = {rel:.2e}")
@@ -146,8 +148,9 @@ def test_k6_config5_n256_321_beads_worm_sector(gpu_lib, oracle, name, threads):
 @pytest.mark.parametrize("names", [["he4_wormbusy_s7", "he4_wormbusy_s8"],
                                    ["he4_worm_s1982", "he4_worm_s1983", "he4_worm_s1984"],
                                    ["he4_bis_cworm0_s1982", "he4_bis_cworm0_s1983"], ["he4_stock_short"]])
-def test_k6_small_runs_full_state(gpu_lib, oracle, names):
+@pytest.mark.parametrize("split", [0, 1])
+def test_k6_small_runs_full_state(gpu_lib, oracle, names, split):
     """The same full-state comparison on the small runs: dozens of accepted swaps, opens and closes, Npw = 1 and 2."""
-    r = run_k6(gpu_lib, oracle, names)
+    r = run_k6(gpu_lib, oracle, names, split=split)
     for w in range(len(names)):
         check_against_driver(r, w)
