@@ -162,7 +162,7 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     c->device = device_id;
     if (const char *ev = getenv("PIGS_K1_VARIANT")) {           // test / tuning hook: same as pigs_set_tuning("k1_variant")
         const int v = atoi(ev);
-        if (v >= K1_AUTO && v <= K1_PIPE2) c->k1_variant = v;
+        if (k1_variant_valid(v)) c->k1_variant = v;
     }
     c->n_walkers = n_walkers;
     DevParams &P = c->P;
@@ -253,7 +253,7 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
 {
     if (!c || !key) return fail(PIGS_ERR_ARG, "null pointer");
     if (!strcmp(key, "k1_variant")) {
-        if (value < K1_AUTO || value > K1_PIPE2) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
+        if (!k1_variant_valid(value)) return fail(PIGS_ERR_ARG, "k1_variant=%d", value);
         c->k1_variant = value;
         return PIGS_OK;
     }
@@ -356,7 +356,7 @@ static int delta_action_host(pigs_ctx *c, int64_t n, const int32_t *walker, cons
     HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xnew.p, xnew, nd * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xold.p, xold, nd * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n, c->d_walker.p, c->d_ip.p,
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, (int)n, c->d_walker.p, c->d_ip.p,
                                c->d_ib.p, c->d_xnew.p, c->d_xold.p, c->d_out.p,
                                parts ? c->d_parts.p : nullptr, s));
     if (DeltaS) HIPCHK(hipMemcpyAsync(DeltaS, c->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -388,7 +388,7 @@ int pigs_delta_action_batch_dev(pigs_ctx *c, int64_t n, const int32_t *d_walker,
     if (n == 0) return PIGS_OK;
     if (!d_walker || !d_ip || !d_ib || !d_xnew || !d_xold || !d_DeltaS) return fail(PIGS_ERR_ARG, "null device pointer");
     // indices are range-checked on the device (out-of-range items produce NaN, never a fault)
-    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n, d_walker, d_ip, d_ib,
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, (int)n, d_walker, d_ip, d_ib,
                                d_xnew, d_xold, d_DeltaS, nullptr, c->stream));
     return PIGS_OK;
 }
@@ -422,7 +422,7 @@ int pigs_delta_action_staged(pigs_ctx *c, int64_t n)
     if (n < 0 || n > c->st_cap) return fail(PIGS_ERR_ARG, "n_items=%lld exceeds the staged capacity %lld", (long long)n, (long long)c->st_cap);
     if (n == 0) return PIGS_OK;
     // indices are range-checked on the device (bad item -> NaN)
-    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_WF, (int)n,
+    HIPCHK(launch_delta_action(c->P, c->k1_variant, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, (int)n,
                                (const int32_t *)c->st_w.d, (const int32_t *)c->st_ip.d, (const int32_t *)c->st_ib.d,
                                (const double *)c->st_xn.d, (const double *)c->st_xo.d, (double *)c->st_out.d,
                                nullptr, c->stream));

@@ -6,21 +6,22 @@
 //
 // Work decomposition: ONE wave64 per item (an item's 255 partners are 4 lane-strided passes
 // over one contiguous 6 KB SoA slice: 512-B coalesced loads per coordinate); no workgroup
-// barrier anywhere in the item loop.  Kernels in this file, in the order they were written (each one
-// selectable with pigs_set_tuning("k1_variant"), measurements in DESIGN.md section 4 and profiles/):
-//   v1  plain statement (IEEE `/`, sqrt(), tables gathered from global memory)
-//   v2  exact short division / fused sqrt+1/r (pigs_device.h), one LDS-transpose reduction for all
-//       accumulators; template flags:
-//         LDSTAB   VTable resident in LDS (80 KB): gathers become ds_read_b64
-//         COMPACT  two passes: (1) distances + cutoff test for all partners, in-cutoff
-//                  (partner, new|old) codes compacted through LDS with ballot/mbcnt;
-//                  (2) the expensive part runs on dense lanes only
-//         PREFETCH all partner loads of an item issued up front
-//         FAST     the short arithmetic (~1 ulp per term, same cutoff decisions; pigs_device.h FastTab)
-//       v1 and v2 without FAST sum bit-identical per-pair terms; only the summation order differs.
-//   pipe / pipe2  persistent, one 1024-thread workgroup per CU, table image with its zero cell in LDS,
-//       branch-free short arithmetic, per-workgroup item queue; pipe2 (the default for large launches of a
-//       periodic system) also requests item records and partner coordinates ahead of their use.
+// barrier anywhere in the item loop.  Kernels in this file (pigs_set_tuning("k1_variant"); measurements in
+// DESIGN.md section 4 and profiles/; the A/B history of the forms that lost -- LDS table in the plain grid,
+// in-cutoff compaction, prefetch-only, the first persistent kernel -- is archived in profiles/r01_k1_variants_ab*.txt):
+//    1 v1    plain statement (IEEE `/`, sqrt(), tables gathered from global memory)
+//    2 v2    exact-term: exact short division / fused sqrt+1/r (pigs_device.h), one LDS-transpose reduction for all
+//            accumulators.  v1 and v2 sum bit-identical per-pair terms; only the summation order differs.
+//    7 / 8   v2 with the short arithmetic on the global table (FastTab; 8: partner loads issued up front) -- the
+//            form for Np > 256
+//   12 pipe2 persistent, one 1024-thread workgroup per CU, table image with its zero cell in LDS, branch-free short
+//            arithmetic, per-workgroup item queue, item records and partner coordinates requested ahead: the default
+//            for large launches of a periodic system with Np <= 256
+//   13 grid  the SAME per-item arithmetic as pipe2 (pipe_pair on the global table image, passes and sides in the same
+//            order) on a plain grid: what small launches of such a system run, so that an item's Delta S does not
+//            depend on how many other items share its launch
+//   14 reference order (validation): exact-term arithmetic, per-partner terms parked in LDS and added by one lane
+//            per accumulator in the reference's jp order -- every bit of Delta S equals the reference's
 #include "pigs_device.h"
 #include "pigs_k1_device.h"
 #include "pigs_kernels.h"
@@ -164,13 +165,12 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 
 
 // =====================================================================================
-// K1 v2
+// K1 v2 (exact-term; FAST: short arithmetic on the global table)
 // =====================================================================================
-// LDS layout (dynamic): [VTable copy: Nmax+2 doubles, if LDSTAB][per wave: kWaveLds bytes = reduction
-// scratch (8 x 65 doubles), whose head doubles as the 512 x u16 code list of COMPACT]
-template <int DIM, bool TRAP, bool LDSTAB, bool COMPACT, int BLOCK, bool PREFETCH = false, bool FAST = false>
+// LDS (dynamic): per wave kWaveLds bytes of reduction scratch (8 x 65 doubles)
+template <int DIM, bool TRAP, int BLOCK, bool PREFETCH = false, bool FAST = false>
 __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
-    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
     const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
     const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
     const double *__restrict__ xnew, const double *__restrict__ xold,
@@ -181,20 +181,7 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
     const int wid   = threadIdx.x >> 6;
     const int nwave = gridDim.x * (BLOCK >> 6);
     const size_t sl = slice_doubles(DIM, P.NpPad);
-
-    const double *VT = VTg;
-    size_t off = 0;
-    if (LDSTAB) {
-        double *tab = reinterpret_cast<double *>(smem);
-        const int nt = P.Nmax + 2;
-        for (int t = threadIdx.x; t < nt; t += BLOCK) tab[t] = VTg[t];
-        off = ((size_t)nt * sizeof(double) + 15) & ~(size_t)15;
-        __syncthreads();
-        VT = tab;
-    }
-    unsigned char *wave_lds = smem + off + (size_t)wid * kWaveLds;
-    unsigned short *codes = reinterpret_cast<unsigned short *>(wave_lds);
-    double *red = reinterpret_cast<double *>(wave_lds);
+    double *red = reinterpret_cast<double *>(smem + (size_t)wid * kWaveLds);
 
     for (int item = blockIdx.x * (BLOCK >> 6) + wid; item < n_items; item += nwave) {
         const int it = __builtin_amdgcn_readfirstlane(item);
@@ -212,15 +199,9 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
             xo[k] = xold[(size_t)it * DIM + k];
         }
         const double *S = paths + ((size_t)w * P.M + b) * sl;
-        const bool odd  = (b & 1) != 0;                         // UpdateAction: force term on odd beads
-        const bool endb = (b == 0) || (b == 2 * P.Nb);          // UpdateWf only on the two end beads
         double *o = out + it;
         double *q = parts ? parts + (size_t)it * 3 : nullptr;
-        if (COMPACT && !TRAP) {
-            if (odd)       item_compact<DIM, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
-            else if (endb) item_compact<DIM, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
-            else           item_compact<DIM, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, codes, red, o, q);
-        } else if (FAST && !TRAP) {                             // short arithmetic (pigs_device.h, FastTab)
+        if (FAST && !TRAP) {                                    // short arithmetic (pigs_device.h, FastTab)
             if (PREFETCH) item_eval_prefetch<DIM, TRAP>(P, FastTab{VT}, WF, S, p, b, xn, xo, lane, red, o, q);
             else          item_eval<DIM, TRAP>(P, FastTab{VT}, WF, S, p, b, xn, xo, lane, red, o, q);
         } else if (PREFETCH) {
@@ -232,47 +213,162 @@ __global__ __launch_bounds__(BLOCK) void k_delta_action_v2(
 }
 
 // =====================================================================================
-// K1 "pipe": the short-arithmetic item evaluation as a persistent, software-pipelined kernel
-// (PBC, Np <= 256).  One 1024-thread workgroup per CU keeps the VTable in LDS -- the table gather was
-// what kept the texture addresser 60-65 % busy in v2 and held every wave on s_waitcnt -- and every
-// wave requests an item's partner coordinates (4 passes x DIM loads) up front and evaluates the two
-// distances of a pass as branch-free, independent chains (masked lanes enter the sums with weight 0);
-// LDS gathers count on lgkmcnt, so they never wait for outstanding global loads; the waves of a workgroup
-// draw its items from an LDS counter (odd beads cost twice the even ones).  Measured and dropped: a rolling
-// two-pass lookahead into the NEXT item's slice and vector-loaded item records (both slower).
+// K1 "grid" (variant 13): pipe2's per-item arithmetic on a plain grid -- pipe_pair on the global table image
+// (pigs_k1_device.h: item_eval_pipe = the four passes in order, new distance then old, the same accumulators and
+// the same reduction as pipe2_item).  Small launches of a periodic system run this, large ones pipe2: the bits of an
+// item's Delta S do not depend on the launch it travels in (a walker's Metropolis chain in the host-driven sampler
+// must not depend on how many walkers share the stage or on how they are sharded over GPUs).
 // =====================================================================================
 template <int DIM>
-struct ItemRec {
-    int    p, b, ok;                       // wave-uniform
-    double xn[DIM], xo[DIM];
-    double rj[4][DIM];                     // partner coordinates of the four passes
-};
-
-template <int DIM>
-__device__ __forceinline__ void pipe_fetch(const DevParams &P, const double *__restrict__ paths, int it,
-                                           const int32_t *__restrict__ walker, const int32_t *__restrict__ ipv,
-                                           const int32_t *__restrict__ ibv, const double *__restrict__ xnew,
-                                           const double *__restrict__ xold, int lane, size_t sl, ItemRec<DIM> &R)
+__global__ __launch_bounds__(256) void k_delta_action_grid(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTimg,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
 {
-    const int w = walker[it];
-    R.p = ipv[it] - 1;
-    R.b = ibv[it];
-    R.ok = (unsigned)w < (unsigned)P.nW && (unsigned)R.p < (unsigned)P.Np && (unsigned)R.b < (unsigned)P.M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane  = threadIdx.x & (kWave - 1);
+    const int wid   = threadIdx.x >> 6;
+    const int nwave = gridDim.x * 4;
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+    double *red = reinterpret_cast<double *>(smem + (size_t)wid * kWaveLds);
+    const PipeTab VT{VTimg + 2, P.Nmax + 3};
+
+    for (int item = blockIdx.x * 4 + wid; item < n_items; item += nwave) {
+        const int it = __builtin_amdgcn_readfirstlane(item);
+        const int w  = walker[it];
+        const int p  = ipv[it] - 1;
+        const int b  = ibv[it];
+        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
+            if (lane == 0) out[it] = __builtin_nan("");
+            continue;
+        }
+        double xn[DIM], xo[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) {
-        R.xn[k] = xnew[(size_t)it * DIM + k];
-        R.xo[k] = xold[(size_t)it * DIM + k];
-    }
-    const double *S = paths + (R.ok ? ((size_t)w * P.M + R.b) * sl : 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int j  = m * kWave + lane;
-        const int jj = j < P.Np ? j : 0;                              // in-bounds dummy for idle lanes
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) R.rj[m][k] = S[(size_t)k * P.NpPad + jj];
+        for (int k = 0; k < DIM; ++k) {
+            xn[k] = xnew[(size_t)it * DIM + k];
+            xo[k] = xold[(size_t)it * DIM + k];
+        }
+        item_eval_pipe<DIM>(P, VT, WF, paths + ((size_t)w * P.M + b) * sl, p, b, xn, xo, lane, red, out + it,
+                            parts ? parts + (size_t)it * 3 : nullptr);
     }
 }
 
+// =====================================================================================
+// K1 "reference order" (variant 14, validation): one wave per item, one item per workgroup.  Every partner's terms
+// are computed with the exact-term arithmetic (bit-identical to the reference's per-pair terms) and parked in LDS
+// (Np x 8 doubles); then lane q adds column q over jp = 1..Np in the reference's order (vpi_mod.f90:2697-2823:
+// PotNew, PotOld, Fnew(k), Fold(k); UpdateWf 2580-2650: PsiNew, PsiOld), starting from the trap's one-body terms
+// exactly where the reference starts from them.  A partner outside the cutoff parks +0.0, which leaves a sum's bits
+// alone.  Delta S then equals the reference's bit for bit -- BASELINE config 2's "pair-action kernel vs CPU
+// bit-compare" taken literally (tests/test_gpu_parity.py::test_reference_order_kernel_is_bit_identical).
+// =====================================================================================
+template <int DIM, bool TRAP, int CLS>
+__device__ __forceinline__ void reforder_item(const DevParams &P, const double *__restrict__ VT, const double *__restrict__ WF,
+                                              const double *__restrict__ S, int p, int b, const double (&xn)[DIM],
+                                              const double (&xo)[DIM], int lane, double *T, double *out, double *parts)
+{
+    // columns: 0 potN 1 potO 2..4 fN 5..7 fO (odd) / 2 psiN 3 psiO (end)
+    for (int j = lane; j < P.Np; j += kWave) {
+        Acc<DIM, CLS> A;
+        if (j != p) {
+            double rj[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + j];
+            partner_accumulate_at<DIM, TRAP, CLS>(P, VT, WF, rj, xn, xo, A);
+        }
+        double *t = T + (size_t)j * 8;
+        t[0] = A.potN; t[1] = A.potO;
+        if (CLS == CLS_ODD) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) { t[2 + k] = A.fN[k]; t[5 + k] = A.fO[k]; }
+        } else if (CLS == CLS_END) {
+            t[2] = A.psiN; t[3] = A.psiO;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    double s = 0.0;
+    if (lane < 8) {
+        if (TRAP) {                                               // the one-body terms come first: vpi_mod.f90:2688-2695, 2555-2560
+            Acc<DIM, CLS> A0;
+            trap_terms<DIM, TRAP, CLS>(P, xn, xo, A0);
+            double col[8] = {A0.potN, A0.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (CLS == CLS_ODD) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) { col[2 + k] = A0.fN[k]; col[5 + k] = A0.fO[k]; }
+            } else if (CLS == CLS_END) {
+                col[2] = A0.psiN; col[3] = A0.psiO;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (lane == q) s = col[q];
+        }
+        for (int j = 0; j < P.Np; ++j) {
+            if (j == p) continue;                                 // vpi_mod.f90:2699
+            s = s + T[(size_t)j * 8 + lane];
+        }
+    }
+    const double c0 = read_lane(s, 0), c1 = read_lane(s, 1);
+    double dF2 = 0.0, dPsi = 0.0;
+    if (CLS == CLS_ODD) {
+        double fn2 = 0.0, fo2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double a = read_lane(s, 2 + k), c = read_lane(s, 5 + k);
+            fn2 = fn2 + a * a;                                    // :2831-2832
+            fo2 = fo2 + c * c;
+        }
+        dF2 = fn2 - fo2;                                          // :2835
+    } else if (CLS == CLS_END) {
+        dPsi = read_lane(s, 2) - read_lane(s, 3);                 // :2653
+    }
+    const double dPot = c0 - c1;                                  // :2838
+    if (lane == 0) {
+        *out = -dPsi + green_function(0, b, P.Nb, P.dt, dPot, dF2);   // :2527 (plain IEEE divisions)
+        if (parts) { parts[0] = dPot; parts[1] = dF2; parts[2] = dPsi; }
+    }
+}
+
+template <int DIM, bool TRAP>
+__global__ __launch_bounds__(64) void k_delta_action_reforder(
+    DevParams P, const double *__restrict__ paths, const double *__restrict__ VT,
+    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
+    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
+    const double *__restrict__ xnew, const double *__restrict__ xold,
+    double *__restrict__ out, double *__restrict__ parts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *T = reinterpret_cast<double *>(smem);
+    const int lane = threadIdx.x;
+    const size_t sl = slice_doubles(DIM, P.NpPad);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int w = walker[it], p = ipv[it] - 1, b = ibv[it];
+        if ((unsigned)w >= (unsigned)P.nW || (unsigned)p >= (unsigned)P.Np || (unsigned)b >= (unsigned)P.M) {
+            if (lane == 0) out[it] = __builtin_nan("");
+            continue;
+        }
+        double xn[DIM], xo[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            xn[k] = xnew[(size_t)it * DIM + k];
+            xo[k] = xold[(size_t)it * DIM + k];
+        }
+        const double *S = paths + ((size_t)w * P.M + b) * sl;
+        double *o = out + it;
+        double *q = parts ? parts + (size_t)it * 3 : nullptr;
+        const bool odd  = (b & 1) != 0;
+        const bool endb = (b == 0) || (b == 2 * P.Nb);
+        if (odd)       reforder_item<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, b, xn, xo, lane, T, o, q);
+        else if (endb) reforder_item<DIM, TRAP, CLS_END>(P, VT, WF, S, p, b, xn, xo, lane, T, o, q);
+        else           reforder_item<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, b, xn, xo, lane, T, o, q);
+        __syncthreads();
+    }
+}
+
+// =====================================================================================
+// Pieces of the persistent kernel: the LDS image of the VTable
+// =====================================================================================
 __device__ __forceinline__ size_t pipe_tab_bytes(int nt) { return ((size_t)(nt + 6) * sizeof(double) + 15) & ~(size_t)15; }
 
 // Staging the table image with the LDS-DMA form of the global load (global_load_lds_dwordx4: 16 bytes per lane
@@ -310,87 +406,15 @@ __device__ __forceinline__ PipeTab pipe_table_dma_finish(unsigned char *smem, co
     return PipeTab{tab, nt + 1};
 }
 
-template <int DIM, int CLS>
-__device__ __forceinline__ void pipe_item(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
-                                          const ItemRec<DIM> &R, int lane, double *red, double *out, double *parts)
-{
-    Acc<DIM, CLS> A;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int j = m * kWave + lane;
-        const bool valid = j < P.Np && j != R.p;                      // row p itself never enters (vpi_mod.f90:2699)
-        double dn[DIM], dold[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            // opaque per (class, pass): keeps the optimiser from hoisting the distance arithmetic of all four
-            // passes above the class branch (it did: 24 live doubles more, spills)
-            double rj = R.rj[m][k];
-            asm volatile("; class %1 pass" : "+v"(rj) : "n"(CLS));
-            dn[k] = R.xn[k] - rj; dold[k] = R.xo[k] - rj;
-        }
-        const double r2o = min_image_rn<DIM>(dold, P);
-        const double r2n = min_image_rn<DIM>(dn, P);
-        pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
-        pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
-        __builtin_amdgcn_sched_barrier(0);                            // two chains in flight, not eight (VGPRs)
-    }
-    finish_item<DIM, CLS>(P, lane, R.b, A, red, out, parts);
-}
-
-template <int DIM>
-__global__ __launch_bounds__(1024) void k_delta_action_pipe(
-    DevParams P, const double *__restrict__ paths, const double *__restrict__ VTg,
-    const double *__restrict__ WF, int n_items, const int32_t *__restrict__ walker,
-    const int32_t *__restrict__ ipv, const int32_t *__restrict__ ibv,
-    const double *__restrict__ xnew, const double *__restrict__ xold,
-    double *__restrict__ out, double *__restrict__ parts)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int next_local;                                  // this workgroup's item queue
-    const int lane  = threadIdx.x & (kWave - 1);
-    const int wid   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t sl = slice_doubles(DIM, P.NpPad);
-
-    // Items blockIdx.x + k*gridDim.x belong to this workgroup (consecutive items -- one walker's beads, odd and
-    // even ones costing 2:1 -- spread over all CUs); its 16 waves take them from an LDS counter as they
-    // become free, so no wave idles behind a neighbour that drew the expensive items.
-    const int n_local = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    int k = wid;
-    ItemRec<DIM> cur;
-    const int nt = P.Nmax + 2;
-    pipe_table_dma_issue(smem, VTg, nt, wid, lane);
-    // the first item's slice is requested while the table is on its way: the two latencies overlap
-    if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
-    const PipeTab VT = pipe_table_dma_finish(smem, VTg, nt);
-    if (threadIdx.x == 0) next_local = 16;
-    double *red = reinterpret_cast<double *>(smem + pipe_tab_bytes(nt) + (size_t)wid * kWaveLds);
-    __syncthreads();                                            // the only workgroup barrier
-
-    while (k < n_local) {
-        const int it = (int)blockIdx.x + k * (int)gridDim.x;
-        int kn = 0;
-        if (lane == 0) kn = atomicAdd(&next_local, 1);
-        k = __builtin_amdgcn_readfirstlane(kn);
-        double *o = out + it;
-        double *q = parts ? parts + (size_t)it * 3 : nullptr;
-        if (!cur.ok) {
-            if (lane == 0) *o = __builtin_nan("");
-        } else {
-            const bool odd  = (cur.b & 1) != 0;
-            const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
-            if (odd)       pipe_item<DIM, CLS_ODD>(P, VT, WF, cur, lane, red, o, q);
-            else if (endb) pipe_item<DIM, CLS_END>(P, VT, WF, cur, lane, red, o, q);
-            else           pipe_item<DIM, CLS_EVEN>(P, VT, WF, cur, lane, red, o, q);
-        }
-        if (k < n_local) pipe_fetch<DIM>(P, paths, (int)blockIdx.x + k * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane, sl, cur);
-    }
-}
-
 // =====================================================================================
-// K1 "pipe2": the pipe kernel with the per-item stall taken out of the critical path.  In `pipe` a wave
-// starts every item with a dependent chain -- scalar loads of the item record, then the slice loads whose
-// address they give, ~3 us -- and with 4 waves per SIMD nothing can cover all of it (78 % VALU occupancy in
-// steady state).  Here (a) the record of the item AFTER the next one is requested with vector loads
+// K1 "pipe2": the short-arithmetic item evaluation as a persistent, software-pipelined kernel (PBC, Np <= 256).
+// One 1024-thread workgroup per CU keeps the VTable image in LDS -- the table gather was what kept the texture
+// addresser 60-65 % busy in v2 and held every wave on s_waitcnt; LDS gathers count on lgkmcnt, so they never wait
+// for outstanding global loads -- and its 16 waves draw the workgroup's items (blockIdx + k*gridDim: one walker's
+// consecutive beads spread over all CUs) from an LDS counter, because odd beads cost more than even ones.  The two
+// distances of a pass are branch-free, independent chains (masked lanes look up the table's zero cell).  A wave
+// that started every item with its dependent chain -- scalar loads of the item record, then the slice loads whose
+// address they give, ~3 us -- reached 78 % VALU occupancy; here (a) the record of the item AFTER the next one is requested with vector loads
 // (lanes 0..2: walker/ip/ib, lanes 0..2*DIM-1: xnew,xold; vmcnt is in order, unlike scalar loads it does not
 // force an lgkmcnt drain at the next LDS gather) and decoded one item later with v_readlane, (b) the
 // partner coordinates run two passes ahead: pass m+2 of this item, then passes 0/1 of the next item, are
@@ -460,11 +484,11 @@ __device__ __forceinline__ const double *pipe2_slice(const DevParams &P, const d
 }
 
 template <int DIM>
-__device__ __forceinline__ void pipe2_load(const DevParams &P, const double *__restrict__ S, int m, int lane,
+__device__ __forceinline__ void pipe2_load(const DevParams &P, const double *__restrict__ S, int p, int m, int lane,
                                            double (&rj)[DIM])
 {
     const int j  = m * kWave + lane;
-    const int jj = j < P.Np ? j : 0;                                  // in-bounds dummy for idle lanes
+    const int jj = pipe_row(P, j, p);                                 // never the moved particle's own row
 #pragma unroll
     for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + jj];
 }
@@ -479,7 +503,8 @@ __device__ __forceinline__ void pipe2_pass(const DevParams &P, PipeTab VT, const
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         double rj = rjm[k];
-        asm volatile("; class %1 pass %2" : "+v"(rj) : "n"(CLS), "n"(M));     // see pipe_item
+        asm volatile("; class %1 pass %2" : "+v"(rj) : "n"(CLS), "n"(M));     // opaque per (class, pass): keeps the optimiser
+                                                                              // from hoisting all four passes' distance arithmetic above the class branch (spills)
         dn[k] = R.xn[k] - rj; dold[k] = R.xo[k] - rj;
     }
     const double r2o = min_image_rn<DIM>(dold, P);
@@ -511,9 +536,9 @@ __device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const
 {
     Acc<DIM, CLS> A;
     double b0[DIM], b1[DIM];
-    pipe2_load<DIM>(P, R.S, 2, lane, b0);
+    pipe2_load<DIM>(P, R.S, R.p, 2, lane, b0);
     pipe2_pass<DIM, CLS, 0>(P, VT, WF, R, st.a0, lane, A);
-    pipe2_load<DIM>(P, R.S, 3, lane, b1);
+    pipe2_load<DIM>(P, R.S, R.p, 3, lane, b1);
     pipe2_pass<DIM, CLS, 1>(P, VT, WF, R, st.a1, lane, A);
     // the next item's record arrived an item ago; the one after it is drawn from the queue and requested now
     // no next item: the look-ahead loads still run (a branch here costs 40 spilled VGPRs) but read `idle`, a
@@ -528,9 +553,10 @@ __device__ __forceinline__ void pipe2_item(const DevParams &P, PipeTab VT, const
                                                                       // slice is in L2: the look-ahead loads cost no HBM traffic)
         st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + kq * (int)gridDim.x, walker, ipv, ibv, xnew, xold, lane);
     }
-    pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
+    const int pnext = __builtin_amdgcn_readlane(st.raw_next.i, 1) - 1;    // (a wave without a next item re-reads a stale record: any row does)
+    pipe2_load<DIM>(P, Snext, pnext, 0, lane, st.a0);
     pipe2_pass<DIM, CLS, 2>(P, VT, WF, R, b0, lane, A);
-    pipe2_load<DIM>(P, Snext, 1, lane, st.a1);
+    pipe2_load<DIM>(P, Snext, pnext, 1, lane, st.a1);
     pipe2_pass<DIM, CLS, 3>(P, VT, WF, R, b1, lane, A);
     finish_item<DIM, CLS>(P, lane, R.b, A, red, out, parts);
 }
@@ -562,8 +588,8 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
         st.raw_next = pipe2_request<DIM>((int)blockIdx.x + (k_nx < n_local ? k_nx : (k_cur < n_local ? k_cur : 0)) * (int)gridDim.x,
                                          walker, ipv, ibv, xnew, xold, lane);
         pipe2_decode<DIM>(P, paths, r0, sl, cur);
-        pipe2_load<DIM>(P, cur.S, 0, lane, st.a0);
-        pipe2_load<DIM>(P, cur.S, 1, lane, st.a1);
+        pipe2_load<DIM>(P, cur.S, cur.p, 0, lane, st.a0);
+        pipe2_load<DIM>(P, cur.S, cur.p, 1, lane, st.a1);
     }
 
     const PipeTab VT = pipe_table_dma_finish(smem, VTg, nt);
@@ -587,8 +613,9 @@ __global__ __launch_bounds__(1024) void k_delta_action_pipe2(
             st.k_nn = kn;
             st.raw_nn = pipe2_request<DIM>((int)blockIdx.x + (kn < n_local ? kn : k_cur) * (int)gridDim.x,
                                            walker, ipv, ibv, xnew, xold, lane);
-            pipe2_load<DIM>(P, Snext, 0, lane, st.a0);
-            pipe2_load<DIM>(P, Snext, 1, lane, st.a1);
+            const int pnext = __builtin_amdgcn_readlane(st.raw_next.i, 1) - 1;
+            pipe2_load<DIM>(P, Snext, pnext, 0, lane, st.a0);
+            pipe2_load<DIM>(P, Snext, pnext, 1, lane, st.a1);
         } else {
             const bool odd  = (cur.b & 1) != 0;
             const bool endb = (cur.b == 0) || (cur.b == 2 * P.Nb);
@@ -671,30 +698,26 @@ static hipError_t set_lds(K kern, size_t bytes)
 }
 
 hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,
-                               const double *WF, int n_items, const int32_t *walker,
+                               const double *VTimg, const double *WF, int n_items, const int32_t *walker,
                                const int32_t *ip, const int32_t *ib, const double *xnew,
                                const double *xold, double *out, double *parts, hipStream_t st)
 {
     if (n_items <= 0) return hipSuccess;
-    const size_t tab_bytes  = (((size_t)(P.Nmax + 2) * sizeof(double)) + 15) & ~(size_t)15;
-    const bool can_compact  = !P.trap && P.Np <= 256;          // 8 code slots per lane
     const size_t pipe_bytes = (((size_t)(P.Nmax + 2 + 6) * sizeof(double)) + 15) & ~(size_t)15;   // pipe_tab_bytes()
-    const bool can_ldstab   = pipe_bytes + 16 * kWaveLds <= 160 * 1024;
+    const bool can_pipe = !P.trap && P.Np <= 256 && VTimg && pipe_bytes + 16 * kWaveLds <= 160 * 1024;
     if (variant == K1_AUTO) {
-        // short arithmetic wherever there is a cutoff; the persistent LDS-table kernel once a launch has
-        // enough items to fill its 16 waves per CU several times over, the plain grid below that
+        // The arithmetic form follows from the SYSTEM, never from the size of the launch: trapped systems the exact-term
+        // form; periodic systems with Np <= 256 the pipe arithmetic -- persistent LDS-table kernel once a launch fills its
+        // 16 waves per CU several times over, the same per-item code on a plain grid below that (identical bits);
+        // periodic systems beyond 256 particles the short arithmetic on the global table.
         if (P.trap) variant = K1_V2;
-        else if (P.Np <= 256 && can_ldstab && n_items >= 16 * k1_pipe_blocks()) variant = K1_PIPE2;
-        else variant = P.Np <= 256 ? K1_FAST_PREFETCH : K1_FAST;
+        else if (can_pipe) variant = (n_items >= 16 * k1_pipe_blocks() && !parts) ? K1_PIPE2 : K1_GRID;
+        else variant = K1_FAST;
     }
-    if ((variant == K1_V2_LDS_COMPACT || variant == K1_V2_COMPACT) && !can_compact) variant = K1_V2;
-    if ((variant == K1_V2_LDS || variant == K1_V2_LDS_COMPACT) && !can_ldstab) variant = K1_V2;
-    if (variant == K1_V2_PREFETCH && P.Np > 256) variant = K1_V2;
+    if ((variant == K1_PIPE2 || variant == K1_GRID) && !can_pipe) variant = P.trap ? K1_V2 : K1_FAST;
+    if (variant == K1_PIPE2 && parts) variant = K1_GRID;        // pipe2 has no registers to spare for the diagnostic output: same arithmetic on the grid
     if (variant == K1_FAST_PREFETCH && P.Np > 256) variant = K1_FAST;
-    if ((variant == K1_FAST_LDS || variant == K1_FAST_LDS_PREFETCH) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
-    if ((variant == K1_PIPE || variant == K1_PIPE2) && (!can_ldstab || P.Np > 256)) variant = K1_FAST;
-    if (variant == K1_PIPE2 && parts) variant = K1_FAST_PREFETCH;      // pipe2 has no registers to spare for the diagnostic output
-    if (variant >= K1_FAST && P.trap) variant = K1_V2;   // no cutoff in the trap: exact path
+    if ((variant == K1_FAST || variant == K1_FAST_PREFETCH) && P.trap) variant = K1_V2;   // no cutoff in the trap: exact path
     hipError_t e = hipSuccess;
     switch (variant) {
     case K1_V1: {
@@ -705,97 +728,33 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
 #undef CALL
         break;
     }
-    case K1_V2: {
-        const size_t lds = 4 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256>), dim3(k1_grid(n_items, 4, 1 << 22)),   \
-                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
-    case K1_V2_PREFETCH: {
-        const size_t lds = 4 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
-                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
-    case K1_FAST: {
-        const size_t lds = 4 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, false, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
-                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
+    case K1_V2:
+    case K1_FAST:
     case K1_FAST_PREFETCH: {
         const size_t lds = 4 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    hipLaunchKernelGGL((k_delta_action_v2<D, T, false, false, 256, true, true>), dim3(k1_grid(n_items, 4, 1 << 22)), \
-                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
+        const int grid = k1_grid(n_items, 4, 1 << 22);
+#define CALL(D, T)                                                                                             \
+    do {                                                                                                       \
+        if (variant == K1_V2)                                                                                  \
+            hipLaunchKernelGGL((k_delta_action_v2<D, T, 256, false, false>), dim3(grid), dim3(256), lds, st, P, \
+                               paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
+        else if (variant == K1_FAST)                                                                           \
+            hipLaunchKernelGGL((k_delta_action_v2<D, T, 256, false, true>), dim3(grid), dim3(256), lds, st, P, \
+                               paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_delta_action_v2<D, T, 256, true, true>), dim3(grid), dim3(256), lds, st, P,  \
+                               paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
+    } while (0)
         PIGS_DISPATCH(P, CALL);
 #undef CALL
         break;
     }
-    case K1_V2_COMPACT: {
+    case K1_GRID: {
         const size_t lds = 4 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    hipLaunchKernelGGL((k_delta_action_v2<D, false, false, true, 256>), dim3(k1_grid(n_items, 4, 1 << 22)), \
-                       dim3(256), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
-    case K1_V2_LDS: {
-        const size_t lds = tab_bytes + 16 * kWaveLds;
-#define CALL(D, T)                                                                                      \
-    do {                                                                                                \
-        e = set_lds(k_delta_action_v2<D, T, true, false, 1024>, lds);                                   \
-        if (e == hipSuccess)                                                                            \
-            hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024>), dim3(k1_grid(n_items, 16, 256)), \
-                               dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
-    } while (0)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
-    case K1_FAST_LDS:
-    case K1_FAST_LDS_PREFETCH: {
-        const size_t lds = tab_bytes + 16 * kWaveLds;
-        const bool pf = variant == K1_FAST_LDS_PREFETCH;
-#define CALL(D, T)                                                                                      \
-    do {                                                                                                \
-        if (pf) {                                                                                       \
-            e = set_lds(k_delta_action_v2<D, T, true, false, 1024, true, true>, lds);                   \
-            if (e == hipSuccess)                                                                        \
-                hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024, true, true>), dim3(k1_grid(n_items, 16, 256)), \
-                                   dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
-        } else {                                                                                        \
-            e = set_lds(k_delta_action_v2<D, T, true, false, 1024, false, true>, lds);                  \
-            if (e == hipSuccess)                                                                        \
-                hipLaunchKernelGGL((k_delta_action_v2<D, T, true, false, 1024, false, true>), dim3(k1_grid(n_items, 16, 256)), \
-                                   dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
-        }                                                                                               \
-    } while (0)
-        PIGS_DISPATCH(P, CALL);
-#undef CALL
-        break;
-    }
-    case K1_PIPE: {
-        const size_t lds = pipe_bytes + 16 * kWaveLds;
-        int blocks = (n_items + 15) / 16;
-        if (blocks > k1_pipe_blocks()) blocks = k1_pipe_blocks();
+        const int grid = k1_grid(n_items, 4, 1 << 22);
 #define CALLP(D)                                                                                        \
-    do {                                                                                                \
-        e = set_lds(k_delta_action_pipe<D>, lds);                                                       \
-        if (e == hipSuccess)                                                                            \
-            hipLaunchKernelGGL((k_delta_action_pipe<D>), dim3(blocks), dim3(1024), lds, st, P, paths,   \
-                               VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts);                \
-    } while (0)
+    hipLaunchKernelGGL((k_delta_action_grid<D>), dim3(grid), dim3(256), lds, st, P, paths, VTimg, WF,   \
+                       n_items, walker, ip, ib, xnew, xold, out, parts)
         if (P.dim == 1) CALLP(1); else if (P.dim == 2) CALLP(2); else CALLP(3);
 #undef CALLP
         break;
@@ -815,14 +774,16 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
 #undef CALLP
         break;
     }
-    case K1_V2_LDS_COMPACT: {
-        const size_t lds = tab_bytes + 16 * kWaveLds;
+    case K1_REFORDER: {
+        const size_t lds = (size_t)P.Np * 8 * sizeof(double);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        const int grid = n_items < (1 << 16) ? n_items : (1 << 16);
 #define CALL(D, T)                                                                                      \
     do {                                                                                                \
-        e = set_lds(k_delta_action_v2<D, false, true, true, 1024>, lds);                                \
+        e = set_lds(k_delta_action_reforder<D, T>, lds);                                                \
         if (e == hipSuccess)                                                                            \
-            hipLaunchKernelGGL((k_delta_action_v2<D, false, true, true, 1024>), dim3(k1_grid(n_items, 16, 256)), \
-                               dim3(1024), lds, st, P, paths, VT, WF, n_items, walker, ip, ib, xnew, xold, out, parts); \
+            hipLaunchKernelGGL((k_delta_action_reforder<D, T>), dim3(grid), dim3(64), lds, st, P, paths, VT, WF, \
+                               n_items, walker, ip, ib, xnew, xold, out, parts);                        \
     } while (0)
         PIGS_DISPATCH(P, CALL);
 #undef CALL

@@ -298,63 +298,6 @@ __device__ __forceinline__ double item_finish_split(const DevParams &P, int b, i
     return -dPsi + green_function_action(b, P.Nb, P.dt, dPot, dF2);
 }
 
-// one item in two passes: (1) all distances + cutoff, in-cutoff (partner, new|old) codes compacted
-// into the wave's LDS list with ballot/mbcnt; (2) dense lanes re-derive their distance and do the
-// expensive part.  PBC only (TRAP has no cutoff on the new distance), Np <= 256.
-template <int DIM, int CLS, typename VTab>
-__device__ __forceinline__ void item_compact(const DevParams &P, VTab VT, const double *__restrict__ WF,
-                                             const double *__restrict__ S, int p, const double (&xn)[DIM],
-                                             const double (&xo)[DIM], int lane, int b,
-                                             unsigned short *codes, double *red,
-                                             double *out, double *parts)
-{
-    Acc<DIM, CLS> A;
-    const int npass = (P.Np + kWave - 1) / kWave;
-    int count = 0;                                                    // wave-uniform
-    for (int m = 0; m < npass; ++m) {
-        const int j = m * kWave + lane;
-        const bool valid = j < P.Np && j != p;
-        double dnew[DIM], dold[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double rj = valid ? S[(size_t)k * P.NpPad + j] : 0.0;
-            dnew[k] = xn[k] - rj;
-            dold[k] = xo[k] - rj;
-        }
-        const double r2n = min_image_fast<DIM>(dnew, P);
-        const double r2o = min_image_fast<DIM>(dold, P);
-        const bool in_n = valid && r2n <= P.rcut2;
-        const bool in_o = valid && r2o <= P.rcut2;
-        const unsigned long long bn = __ballot(in_n);
-        const unsigned long long bo = __ballot(in_o);
-        const int pn = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bn, 0));
-        count += __builtin_popcountll(bn);
-        const int po = count + __builtin_amdgcn_mbcnt_hi((unsigned)(bo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bo, 0));
-        count += __builtin_popcountll(bo);
-        const unsigned short code = (unsigned short)(((m << 1) << 6) | lane);
-        if (in_n) codes[pn] = code;
-        if (in_o) codes[po] = code | (1u << 6);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < count; t0 += kWave) {
-        const int idx = t0 + lane;
-        if (idx < count) {
-            const unsigned c = codes[idx];
-            const bool is_old = (c >> 6) & 1u;
-            const int j = (int)(c >> 7) * kWave + (int)(c & 63u);
-            double d[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) d[k] = (is_old ? xo[k] : xn[k]) - S[(size_t)k * P.NpPad + j];
-            const double r2 = min_image_fast<DIM>(d, P);
-            if (is_old) pair_accumulate<DIM, CLS, true>(P, VT, WF, r2, d, A);
-            else        pair_accumulate<DIM, CLS, false>(P, VT, WF, r2, d, A);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    finish_item<DIM, CLS>(P, lane, b, A, red, out, parts);
-}
-
-
 template <int DIM, bool TRAP, typename VTab>
 __device__ __forceinline__ void item_eval_prefetch(const DevParams &P, VTab VT, const double *__restrict__ WF,
                                                    const double *__restrict__ S, int p, int b, const double (&xn)[DIM],
@@ -378,6 +321,14 @@ __device__ __forceinline__ void item_eval(const DevParams &P, VTab VT, const dou
     if (odd)       item_direct<DIM, TRAP, CLS_ODD>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
     else if (endb) item_direct<DIM, TRAP, CLS_END>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
     else           item_direct<DIM, TRAP, CLS_EVEN>(P, VT, WF, S, p, xn, xo, lane, b, red, out, parts);
+}
+
+// Row a lane loads in the branch-free forms: its own partner, or -- for a lane without one (beyond Np, or the moved
+// particle's own row, which the aliasing contract says is never read: vpi_mod.f90:2699) -- another particle's row,
+// whose (finite) coordinates are then masked out through the table's zero cell.
+__device__ __forceinline__ int pipe_row(const DevParams &P, int j, int p)
+{
+    return (j < P.Np && j != p) ? j : (p == 0 && P.Np > 1 ? 1 : 0);
 }
 
 // Image of the VTable used by the branch-free evaluation (LDS copy in K1's pipe kernels, a global copy for
@@ -471,7 +422,7 @@ __device__ __forceinline__ void item_direct_pipe(const DevParams &P, PipeTab VT,
 #pragma unroll
     for (int m = 0; m < MAXP; ++m) {
         const int j = m * kWave + lane;
-        const int jj = j < P.Np ? j : 0;                              // in-bounds dummy for idle lanes
+        const int jj = pipe_row(P, j, p);
 #pragma unroll
         for (int k = 0; k < DIM; ++k) rj[m][k] = S[(size_t)k * P.NpPad + jj];
     }
@@ -501,7 +452,7 @@ __device__ __forceinline__ void item_pass_pipe_cls(const DevParams &P, PipeTab V
 {
     Acc<DIM, CLS> A;
     const int j = m * kWave + lane;
-    const int jj = j < P.Np ? j : 0;
+    const int jj = pipe_row(P, j, p);
     double rj[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) rj[k] = S[(size_t)k * P.NpPad + jj];
@@ -557,7 +508,7 @@ __device__ __forceinline__ void pipe_task_cls(const DevParams &P, PipeTab VT, co
         for (int m = 0; m < MAXP; ++m) {
             if (m < nn) {
                 const int j = (mb + m) * kWave + lane;
-                const int jj = j < P.Np ? j : 0;                      // in-bounds dummy for idle lanes
+                const int jj = pipe_row(P, j, p);
 #pragma unroll
                 for (int k = 0; k < DIM; ++k) rj[m][k] = S[(size_t)k * P.NpPad + jj];
             }

@@ -9,25 +9,27 @@
 
 namespace pigs {
 
-// K1 kernel variants (pigs_k1.hip)
+// K1 kernel variants (pigs_k1.hip).  The numbers are part of the tuning interface (pigs_set_tuning "k1_variant");
+// 3-6 and 9-11 were A/B forms of round 1 (LDS table / compaction / prefetch-only / first persistent kernel) that
+// measured slower and are gone: profiles/r01_k1_variants_ab*.txt keeps their numbers.
 enum K1Variant {
-    K1_AUTO = 0,            // library's choice
+    K1_AUTO = 0,            // library's choice (by system, never by launch size: see launch_delta_action)
     K1_V1 = 1,              // plain statement
-    K1_V2 = 2,              // exact short division, fused sqrt/rinv, shared butterfly
-    K1_V2_LDS = 3,          // + VTable in LDS
-    K1_V2_COMPACT = 4,      // + in-cutoff compaction (global table)
-    K1_V2_LDS_COMPACT = 5,  // + both
-    K1_V2_PREFETCH = 6,     // v2 with all partner loads of an item issued up front (Np <= 256)
+    K1_V2 = 2,              // exact-term: exact short division, fused sqrt/rinv, one LDS-transpose reduction
     K1_FAST = 7,            // v2 with the short arithmetic (~1 ulp per term instead of the reference's rounding; PBC)
-    K1_FAST_PREFETCH = 8,   // + prefetch
-    K1_FAST_LDS = 9,        // fast with the VTable in LDS (one 1024-thread workgroup per CU)
-    K1_FAST_LDS_PREFETCH = 10,
-    K1_PIPE = 11,           // persistent: LDS table, branch-free short arithmetic, per-workgroup item queue (Np <= 256)
-    K1_PIPE2 = 12           // + item records and partner coordinates requested one item / two passes ahead
+    K1_FAST_PREFETCH = 8,   // + all partner loads of an item issued up front (Np <= 256)
+    K1_PIPE2 = 12,          // persistent: LDS table image, branch-free short arithmetic, item queue, look-ahead loads (Np <= 256)
+    K1_GRID = 13,           // pipe2's per-item arithmetic on a plain grid (global table image): identical bits, small launches
+    K1_REFORDER = 14        // validation: exact terms added in the reference's jp order -- Delta S bit-identical to the reference
 };
+inline bool k1_variant_valid(int v)
+{
+    return v == K1_AUTO || v == K1_V1 || v == K1_V2 || v == K1_FAST || v == K1_FAST_PREFETCH || v == K1_PIPE2 ||
+           v == K1_GRID || v == K1_REFORDER;
+}
 
 hipError_t launch_delta_action(const DevParams &P, int variant, const double *paths, const double *VT,
-                               const double *WF, int n_items, const int32_t *walker,
+                               const double *VTimg, const double *WF, int n_items, const int32_t *walker,
                                const int32_t *ip, const int32_t *ib, const double *xnew,
                                const double *xold, double *out, double *parts, hipStream_t st);
 
