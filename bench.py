@@ -18,9 +18,15 @@ roofline: HBM bound named by the north star; achieved = ALGORITHMIC bytes per la
 cpu_baseline: the pinned scalar C restatement of the same routine (oracle/, kind "port"),
           timed on this machine's host cores on a bounded sample of the same batch.
 
+roofline_large: the same stage on 3x the walkers (380 MB of worldlines: beyond the 256 MiB Infinity Cache), so
+          that the headline fraction cannot be a cache artefact.
+roofline_k2 / roofline_mc: secondary figures -- K2 (slice energies of ThermEnergy) against the FP64 vector peak,
+          and the device-resident sampler's bead-pair rate against K1's.
+
 N>1 (launched by torch.distributed.run): one process per GPU, walkers shard across ranks (weak
-scaling: 128 walkers per GPU), no data-path collective; one all-reduce of the block-estimator
-vector (RCCL) closes the timed region, as the sampler does once per block.
+scaling: 128 walkers per GPU), no data-path collective in the Delta-S leg; the `mc` leg ends its block with ONE
+all-reduce (RCCL) of the real block-estimator vector (energies and their squares, g(r), S(k), counters:
+sharding.EstimatorVector), as the sampler does once per block, and rank 0 checks the sum.
 """
 import argparse
 import json
@@ -35,12 +41,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 vector peak (the bound of K2 / K4)
+# algorithmic flops of one unordered pair of a slice in K2: distance + minimum image + r^2 (17),
+# sqrt (8), V interpolation (8) on every slice; dV/dr interpolation (10), 1/r (4), force terms on both particles (9) on
+# odd slices -> 33 / 56, 44.5 on average over a chain
+K2_FLOPS_PER_PAIR = 44.5
+TRAFFIC_FILE = os.path.join("profiles", "r02_k1_hbm_traffic.json")
 
 
 # K1 kernel behind each k1_variant on the bench workload (0 = the library's choice: periodic system, Np <= 256,
 # a launch of >= 16 items per CU -> the persistent LDS-table kernel with the short arithmetic)
-K1_KERNELS = {0: "pigs::k_delta_action_pipe2<3>", 11: "pigs::k_delta_action_pipe<3>", 12: "pigs::k_delta_action_pipe2<3>",
-              2: "pigs::k_delta_action_v2<3,false,false,false,256,false,false>"}
+K1_KERNELS = {0: "pigs::k_delta_action_pipe2<3>", 12: "pigs::k_delta_action_pipe2<3>", 13: "pigs::k_delta_action_grid<3>",
+              2: "pigs::k_delta_action_v2<3,false,256,false,false>"}
 
 
 def make_workload(cfg, W, nsets, seed):
@@ -120,6 +132,7 @@ def main():
     ap.add_argument("--nb", type=int, default=80, help="reference namelist Nb (beads = 2*Nb+1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--variant", type=int, default=0, help="K1 kernel variant (0 = library default)")
+    ap.add_argument("--large-walkers", type=int, default=384, help="walkers of the beyond-Infinity-Cache leg (0: skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse "
                                                       "the multi-process path on a one-GPU machine)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -180,8 +193,6 @@ def main():
     for i in range(args.warmup):
         step(i)
     ctx.sync()
-    est = torch.zeros(390, dtype=torch.float64, device=dev)     # block-estimator vector
-
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -191,11 +202,6 @@ def main():
         step(i)
     ev1.record(kstream)
     ctx.sync()
-    if world > 1:
-        if args.backend == "nccl":
-            dist.all_reduce(est)                                # RCCL over xGMI, once per block
-        else:
-            est_h = est.cpu(); dist.all_reduce(est_h); est.copy_(est_h)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,12 +222,60 @@ def main():
     # separate runs, gfx950 FETCH_SIZE x2 correction: profiles/README.md) -- valid for this workload only
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             tj = json.load(f)
         if tj.get("algorithmic_bytes_per_launch") == alg_bytes and tj.get("kernel") == K1_KERNELS.get(args.variant):
             traffic = tj["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+
+    # ---- the same stage on 3x the walkers: 380 MB of worldlines, beyond the 256 MiB Infinity Cache ----------------
+    large = None
+    if args.large_walkers > 0:
+        WL = args.large_walkers
+        PathsL, setsL = make_workload(cfg, WL, 2, seed=4000 + rank)
+        ctxL = api.PigsContext(cfg, VT, WF, n_walkers=WL, device_id=local)
+        ctxL.upload_all(PathsL)
+        del PathsL
+        if args.variant:
+            ctxL.set_tuning("k1_variant", args.variant)
+        dL = [tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in st) for st in setsL]
+        nL = len(setsL[0][0])
+        oL = torch.empty(nL, dtype=torch.float64, device=dev)
+        ksL = torch.cuda.ExternalStream(ctxL.stream(), device=dev)
+
+        def stepL(i):
+            w, ip, ib, xn, xo = dL[i % 2]
+            ctxL.delta_action_batch_dev(nL, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(),
+                                        oL.data_ptr())
+        for i in range(6):
+            stepL(i)
+        ctxL.sync()
+        nstepL = max(10, min(args.steps, 100))
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(ksL)
+        for i in range(nstepL):
+            stepL(i)
+        e1.record(ksL)
+        ctxL.sync()
+        torch.cuda.synchronize()
+        msL = e0.elapsed_time(e1) / nstepL
+        bytesL = nL * (cfg.dim * cfg.Np * 8 + 2 * cfg.dim * 8 + 8)
+        trafficL = None
+        try:
+            tl = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get("large", {})
+            if tl.get("algorithmic_bytes_per_launch") == bytesL:
+                trafficL = tl["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        large = {"bound": "hbm", "walkers": WL, "traffic": trafficL,
+                 "traffic_source": (TRAFFIC_FILE + " (same PMC passes)") if trafficL is not None else None, "working_set_bytes": int(WL * cfg.M * cfg.dim * cfg.Np * 8),
+                 "algorithmic_bytes_per_launch": bytesL, "kernel_ms": msL, "achieved": bytesL / (msL * 1e-3) / 1e9,
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytesL / (msL * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "steps": nstepL, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
+                                          "than the 256 MiB Infinity Cache, so every slice comes from HBM"}
+        ctxL.close()
+        del dL, oL
 
     # ---- second half of BASELINE's metric: MC sweeps / s.  The device-resident sampler (K6) advances
     # every resident walker by whole MC steps (CM move of every particle + Nstag x Np x {head, tail,
@@ -250,22 +304,65 @@ def main():
             mc_el = float(tt.item())
         acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 1))
         # the same steps followed by the diagonal-sector estimators of vpi.f90:443-469 (2 x LocalEnergy K4,
-        # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker: SURVEY 8d's definition of a sweep
+        # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker: SURVEY 8d's definition of a sweep.  The block's
+        # estimator vector (what the front end accumulates per block: vpi.f90:456-469) is filled from them and
+        # all-reduced ONCE at the end of the block, inside the timed region.
+        from pathintegralgroundstate_amd.sharding import EstimatorVector
+        ev = EstimatorVector(Nbin=100, Nk=50, dim=3, Npw=0)
+        c16_0 = ctx.sampler_counters16()
         if world > 1:
             dist.barrier()
         t2 = time.perf_counter()
         for i in range(nmc):
             ctx.sampler_step(2 + nmc + i)
-            ctx.local_energy_batch(0)
-            ctx.local_energy_batch(2 * cfg.Nb)
-            ctx.therm_energy_batch()
-            ctx.structure_batch(cfg.Nb, 100, cfg.rcut / 100.0, 50)
+            E1, _, _ = ctx.local_energy_batch(0)
+            E2, _, _ = ctx.local_energy_batch(2 * cfg.Nb)
+            Et, Kt, Pt = ctx.therm_energy_batch()
+            gr, Sk = ctx.structure_batch(cfg.Nb, 100, cfg.rcut / 100.0, 50)
+            E = 0.5 * (E1 + E2)
+            K = E - Pt
+            ev.add("n_diag", W)
+            for name, v in (("E", E), ("K", K), ("V", Pt), ("Et", Et), ("Kt", Kt), ("Vt", Pt)):
+                ev.add(name, v.sum()); ev.add(name + "2", (v * v).sum())
+            ev.add("gr", gr.sum(0)); ev.add("Sk", Sk.sum(0).T.ravel()); ev.add("ngr", W)
+        c16 = (ctx.sampler_counters16() - c16_0).sum(0)
+        for name, q in (("acc_cm", 0), ("acc_head", 1), ("acc_tail", 2), ("acc_bd", 3), ("try_open", 4), ("try_cm", 14),
+                        ("try_stag", 15)):
+            ev.add(name, float(c16[q]))
+        mine = ev.data.copy()
+        if world > 1:                                           # the one collective of a block: RCCL over xGMI
+            t_est = torch.from_numpy(mine.copy()).to(red_dev)
+            dist.all_reduce(t_est)
+            reduced = t_est.cpu().numpy()
+        else:
+            reduced = mine.copy()
         ctx.sync()
         mc_full = time.perf_counter() - t2
         if world > 1:
             tt = torch.tensor([mc_full], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             mc_full = float(tt.item())
+            # untimed check of the reduction: rank 0 adds the ranks' vectors itself
+            parts_ = [torch.zeros(ev.size, dtype=torch.float64, device=red_dev) for _ in range(world)]
+            dist.all_gather(parts_, torch.from_numpy(mine).to(red_dev))
+            want_sum = np.sum([q.cpu().numpy() for q in parts_], axis=0)
+            assert np.allclose(reduced, want_sum, rtol=1e-12, atol=0), "estimator all-reduce disagrees with the sum of the ranks"
+        assert reduced[ev.fields["n_diag"]][0] == world * W * nmc
+        est_summary = {"length": int(ev.size), "n_diag": float(reduced[ev.fields["n_diag"]][0]),
+                       "E_per_particle": float(reduced[ev.fields["E"]][0] / reduced[ev.fields["n_diag"]][0] / cfg.Np),
+                       "Et_per_particle": float(reduced[ev.fields["Et"]][0] / reduced[ev.fields["n_diag"]][0] / cfg.Np),
+                       "collective": "all_reduce(sum, f64) x1 per block" if world > 1 else "none (one rank)"}
+        # K2 alone (ThermEnergy of every walker: 2Nb slices x Np(Np-1)/2 pairs each) against the FP64 vector peak
+        ctx.therm_energy_batch()
+        t3 = time.perf_counter()
+        for _ in range(5):
+            ctx.therm_energy_batch()
+        k2_ms = 1e3 * (time.perf_counter() - t3) / 5
+        k2_pairs = W * 2 * cfg.Nb * (cfg.Np * (cfg.Np - 1) // 2)
+        k2 = {"bound": "fp64-valu", "kernel": "pigs::k_slice_energy_lds (+ k_therm_combine; host-timed call incl. the result copy)",
+              "ms_per_call": k2_ms, "pairs_per_call": k2_pairs, "flops_per_pair": K2_FLOPS_PER_PAIR,
+              "achieved": k2_pairs * K2_FLOPS_PER_PAIR / (k2_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": k2_pairs * K2_FLOPS_PER_PAIR / (k2_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
         # Delta-S items of one sweep of one walker: Np*(2Nb+1) + the bisection stages actually run;
         # the exact count depends on early exits, so it is bounded by SURVEY 8d's schedule
         mc = {"walker_sweeps_per_s": world * W * nmc / mc_full, "ms_per_mc_step": 1e3 * mc_full / nmc,
@@ -275,7 +372,16 @@ def main():
                          "k_therm_combine, k_structure per step",
               "accepted_moves_per_sweep_per_walker": {"cm": acc[0], "head": acc[1], "tail": acc[2], "bisection": acc[3]},
               "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in), estimators every step",
+              "estimator_vector": est_summary,
               "reference_cpu_sweeps_per_s_per_core": 1.24}
+        # the sampler's bead-pair rate (16.36 M bead-pair Delta-S evaluations per sweep of one walker at this
+        # size and schedule, measured on the reference) against K1's kernel-only rate on the same GPU
+        mc_pairs = 16.36e6 * W * nmc / mc_el
+        mc["roofline"] = {"bound": "K1 rate (hbm)", "pair_evals_per_sweep_per_walker": 16.36e6, "achieved": mc_pairs,
+                          "peak": pair_evals_per_step / (kern_ms * 1e-3), "unit": "bead-pair action evals/s",
+                          "frac": mc_pairs / (pair_evals_per_step / (kern_ms * 1e-3)),
+                          "hbm_frac_equivalent": mc_pairs * alg_bytes / pair_evals_per_step / 1e9 / HBM_PEAK_GBS}
+        mc["roofline_k2"] = k2
     except api.PigsError as exc:       # pragma: no cover
         mc = {"error": str(exc)}
 
@@ -307,9 +413,16 @@ def main():
                        "stages_per_sweep_equiv": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # measured live: kernel_ms (HIP events on the context's stream).  NOT measured in this run:
+                         # `traffic` (PMC passes need rocprofv3) and the kernel's name -- both come from the file below
+                         "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                                           if traffic is not None else None,
                          "kernel": K1_KERNELS.get(args.variant, "pigs::k_delta_action_v2<...> (variant %d)" % args.variant),
+                         "kernel_source": "library dispatch rule (pigs_k1.hip launch_delta_action); confirmed by "
+                                          "profiles/r02_bench_kernel_stats.csv",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_large": large,
             "cpu_baseline": cpu,
             "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),
             "mc": mc,
