@@ -183,7 +183,10 @@ class PigsContext:
             p.Lbox[k] = cfg.Lbox[k]
             p.a_ho[k] = cfg.a_ho[k]
         self._VT = _f64(VTable)
-        self._WF = _f64(LogWF)
+        # wf_table = F (the reference's default): the trial function is evaluated analytically, LogWF may be None
+        self._WF = _f64(LogWF) if LogWF is not None else np.zeros(cfg.Nmax + 2)
+        if LogWF is None and cfg.wf_table:
+            raise ValueError("wf_table = T needs a LogWF table")
         if self._VT.size != cfg.Nmax + 2 or self._WF.size != cfg.Nmax + 2:
             raise PigsError("tables must hold Nmax+2 doubles (F(0:Nmax+1))")
         h = C.c_void_p()

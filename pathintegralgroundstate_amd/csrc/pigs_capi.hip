@@ -146,7 +146,9 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
     // Reference quirk Q3: Force() is an empty stub, so the analytic (table-less) branch is
     // unusable for the force terms; and the kernels consume tables only.
     if (!p->v_table || !VTable) return fail(PIGS_ERR_UNSUPPORTED, "v_table=T with a VTable is mandatory (reference Force() is a stub)");
-    if (!p->wf_table || !LogWF) return fail(PIGS_ERR_UNSUPPORTED, "wf_table=T with a LogWF table is required by the GPU path");
+    // wf_table = F (the reference's default): the trial function is evaluated analytically (McMillan, pigs_device.h
+    // log_psi) and LogWF may be null
+    if (p->wf_table && !LogWF) return fail(PIGS_ERR_ARG, "wf_table=T needs a LogWF table");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -190,7 +192,7 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
         if (hipMalloc((void **)&c->d_WF, tb) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         if (hipMalloc((void **)&c->d_paths, c->path_doubles * n_walkers * sizeof(double)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         if (hipMemcpy(c->d_VT, VTable, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
-        if (hipMemcpy(c->d_WF, LogWF, tb, hipMemcpyHostToDevice) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        if ((LogWF && p->wf_table ? hipMemcpy(c->d_WF, LogWF, tb, hipMemcpyHostToDevice) : hipMemset(c->d_WF, 0, tb)) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         {
             std::vector<double> img((size_t)p->Nmax + 2 + 6, 0.0);
             img[1] = VTable[0];

@@ -374,6 +374,18 @@ __device__ __forceinline__ double green_function_action(int ib, int Nb, double d
     return div_by(4.0 * dt * Vc, 3.0, r3);
 }
 
+// ---- analytic trial function, wf_table = F (the reference's DEFAULT, vpi_mod.f90:59): McMillan u(r) = -0.5 (Rm/r)^5 and
+// its derivatives (system_mod.f90:38-66).  (Rm/r)**5 is a left-to-right product in the reference build (pinned on the
+// oracle); the divisions are IEEE.  Used by the end-bead terms of K1 / K6 and by K4.
+__host__ __device__ inline double log_psi(int opt, double Rm, double r)
+{
+    const double q = Rm / r;
+    const double q5 = q * q * q * q * q;
+    if (opt == 0) return -0.5 * q5;
+    if (opt == 1) return 2.5 * q5 / r;
+    return -15.0 * q5 / (r * r);
+}
+
 // ---- one-body trap terms (system_mod.f90:213-252) -----------------------------------
 __host__ __device__ inline double trap_pot(int opt, double a, double x)
 {

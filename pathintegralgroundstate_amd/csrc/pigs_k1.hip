@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 #pragma unroll
                         for (int k = 0; k < DIM; ++k) fN[k] = fN[k] + dv * dnew[k] / r;   // :2784
                     }
-                    if (endb) psiN = psiN + interp0(WF, L, P.dr);                       // :2638
+                    if (endb) psiN = psiN + (P.wf_table ? interp0(WF, L, P.dr) : log_psi(0, P.Rm, r));   // :2637-2641
                 }
                 if (r2o <= P.rcut2) {                        // :2745 / :2795
                     const double r = sqrt(r2o);
@@ -122,12 +122,12 @@ __global__ __launch_bounds__(256) void k_delta_action_v1(
 #pragma unroll
                         for (int k = 0; k < DIM; ++k) fO[k] = fO[k] + dv * dold[k] / r;   // :2808
                     }
-                    if (endb) psiO = psiO + interp0(WF, L, P.dr);                       // :2624
+                    if (endb) psiO = psiO + (P.wf_table ? interp0(WF, L, P.dr) : log_psi(0, P.Rm, r));   // :2623-2627
                 } else if (TRAP && endb) {
                     // UpdateWf's trap branch has no cutoff on either distance (vpi_mod.f90:2595-2615)
                     const double r = sqrt(r2o);
                     const Lerp L = lerp_setup(r, P.dr, P.Nmax);
-                    psiO = psiO + interp0(WF, L, P.dr);
+                    psiO = psiO + (P.wf_table ? interp0(WF, L, P.dr) : log_psi(0, P.Rm, r));
                 }
             }
         }

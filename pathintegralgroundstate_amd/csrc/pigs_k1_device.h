@@ -55,8 +55,9 @@ __device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, con
                 if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
             }
             if (CLS == CLS_END) {
-                const double *U = WF + C.i0;
-                const double u = __builtin_fma(C.f, U[1], C.omf * U[0]);
+                double u;
+                if (P.wf_table) { const double *U = WF + C.i0; u = __builtin_fma(C.f, U[1], C.omf * U[0]); }
+                else            u = log_psi(0, P.Rm, C.r);                  // analytic trial function (wf_table = F)
                 if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
             }
         }
@@ -80,7 +81,7 @@ __device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, con
             if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
         }
         if (CLS == CLS_END) {
-            const double u = finterp0(WF, L, P);
+            const double u = P.wf_table ? finterp0(WF, L, P) : log_psi(0, P.Rm, r);   // vpi_mod.f90:2599-2645
             if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
         }
     }
@@ -378,9 +379,14 @@ __device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const 
         }
     }
     if (CLS == CLS_END) {                                                 // LogWF stays in global memory (2 of 161 beads)
-        const double *U = WF + (in ? it : 0);
-        const double u0 = U[0], u1 = U[1];
-        const double u  = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;    // (1-f)*(-Inf) keeps the -Inf head (Q4)
+        double u;
+        if (P.wf_table) {
+            const double *U = WF + (in ? it : 0);
+            const double u0 = U[0], u1 = U[1];
+            u = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;              // (1-f)*(-Inf) keeps the -Inf head (Q4)
+        } else {
+            u = in ? log_psi(0, P.Rm, g) : 0.0;                               // analytic trial function (wf_table = F)
+        }
         if (IS_OLD) A.psiO = A.psiO + u; else A.psiN = A.psiN + u;
     }
 }

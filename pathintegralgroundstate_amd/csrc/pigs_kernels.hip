@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void k_local_energy(
             if (TRAP || r2 <= P.rcut2) {                      // :230 / :264
                 const double r = sqrt(r2);
                 const Lerp L = lerp_setup(r, P.dr, P.Nmax);
-                const double dudr   = interp1(WF, L, P.dr);   // :270
-                const double d2udr2 = interp2(WF, L, P.dr);   // :271
+                const double dudr   = P.wf_table ? interp1(WF, L, P.dr) : log_psi(1, P.Rm, r);   // :268-277
+                const double d2udr2 = P.wf_table ? interp2(WF, L, P.dr) : log_psi(2, P.Rm, r);
                 lapi = lapi + (dimm1 * dudr / r + d2udr2);    // :280
 #pragma unroll
                 for (int k = 0; k < DIM; ++k) F[k] = F[k] + dudr * d[k] / r;   // :283-284

@@ -104,8 +104,8 @@ program pigs_vpi
   read (5,nml=jastrow,iostat=ios); rewind (5)
   read (5,nml=gpu,iostat=ios);     rewind (5)
 
-  if (.not. (wf_table .and. v_table)) then
-     write (0,*) 'pigs_vpi: wf_table = T and v_table = T are required (the reference Force() is a stub)'
+  if (.not. v_table) then
+     write (0,*) 'pigs_vpi: v_table = T is required (the reference Force() is a stub: system_mod.f90:186-209)'
      stop 2
   end if
   NW  = n_walkers
@@ -159,7 +159,7 @@ program pigs_vpi
   call pigs_check(pigs_build_tables_kind(int(pot_kind,c_int32_t),int(Nmax,c_int32_t),Rm,rcut,VTable,LogWF,dr), &
        & 'pigs_build_tables_kind')
   gp%dim = dim; gp%Np = Np; gp%Nb = Nb; gp%Nmax = Nmax
-  gp%trap = merge(1,0,trap); gp%wf_table = 1; gp%v_table = 1; gp%reserved = 0
+  gp%trap = merge(1,0,trap); gp%wf_table = merge(1,0,wf_table); gp%v_table = 1; gp%reserved = 0
   gp%dr = dr; gp%rcut2 = rcut2; gp%dt = dt; gp%Rm = Rm
   gp%Lbox = Lbox; gp%a_ho = a_ho
   call pigs_check(pigs_ctx_create(gp,VTable,LogWF,int(NW,c_int32_t),int(device,c_int32_t),ctx),'pigs_ctx_create')
@@ -179,7 +179,12 @@ program pigs_vpi
      if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
      if (resume) then
         open (newunit=ucfg,file='checkpoint'//trim(suffix)//'.dat',status='old')
-        read (ucfg,*) lflag                      ! trap (as written; the namelist value rules)
+        read (ucfg,*) lflag                      ! trap: the reference's init takes it from the file (vpi_mod.f90:166);
+        if (lflag .neqv. trap) then              ! here the tables and the box were already built from the namelist value,
+           write (0,*) 'pigs_vpi: checkpoint',trim(suffix),'.dat was written with trap = ',lflag, &   ! so a mismatch is an error
+                & ' but the namelist says trap = ',trap
+           stop 2
+        end if
         read (ucfg,*) lflag
         s%isopen(w) = lflag
         read (ucfg,*) s%iworm(w)

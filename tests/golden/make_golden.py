@@ -33,7 +33,7 @@ VPI_IN = """&system
  swapping = T, CWorm = {CWorm}, Nobdm = {Nobdm}, Npw = {Npw}
 /
 &wavefun
- Nmax = 10000, wf_table = T, v_table = T
+ Nmax = 10000, wf_table = {wf_table}, v_table = T
 /
 &jastrow
  Rm = 1.20d0
@@ -48,7 +48,7 @@ def run_vpi(workdir, **kw):
     """Run the stock reference program; returns the checkpointed worldline (M,Np,dim)."""
     p = dict(dim=3, Np=64, density="0.365d0", trap="F", dt="5.0d-3", Nb=40, seed=1982,
              sampling="bis", Lstag=16, Nlev=4, Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0",
-             Nobdm=0, Npw=0, a_ho="1.0d0")
+             Nobdm=0, Npw=0, a_ho="1.0d0", wf_table="T")
     p.update(kw)
     with open(os.path.join(workdir, "vpi.in"), "w") as f:
         f.write(VPI_IN.format(**p))
@@ -228,6 +228,9 @@ RUNS = {
                              Nblock=2, Nstep=6, CWorm="0.0d0", Nobdm=0, Npw=0, driver=False),
     "lstag_gt_nb_sta": dict(dim=2, Np=12, Nb=10, density="0.1d0", seed=77, sampling="sta", Lstag=15, Nlev=2, Nstag=2,
                             Nblock=2, Nstep=6, CWorm="0.0d0", Nobdm=0, Npw=0, driver=False),
+    # wf_table = F, the reference's default: the McMillan trial function evaluated analytically (system_mod.f90:38-66)
+    "he4_wf_analytic": dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
+                            Nblock=4, Nstep=20, CWorm="0.5d0", Nobdm=4, Npw=1, wf_table="F"),
     # ---- BASELINE sizes ------------------------------------------------------------------------
     # C3: liquid 4He N=256, 161 beads, stock schedule, CWorm = 0
     "c3_n256_s1982": dict(dim=3, Np=256, Nb=80, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
@@ -261,7 +264,7 @@ def drive_run(ref, kw, VT=None):
         density = SystemConfig(dim=kw["dim"], Np=kw["Np"], Nb=kw["Nb"], trap=True, a_ho=a_ho).density   # vpi.f90:82-93
     S = System(dim=kw["dim"], Np=kw["Np"], Nb=kw["Nb"], density=density,
                dt=_fnum(kw.get("dt", "5.0d-3")), trap=trap, a_ho=a_ho if trap else None,
-               CWorm=_fnum(kw["CWorm"]), Npw=kw["Npw"], Nbin=100)
+               CWorm=_fnum(kw["CWorm"]), Npw=kw["Npw"], Nbin=100, wf_table=kw.get("wf_table", "T") == "T")
     VTr, WF = ref.tables(S)
     if VT is None:
         VT = VTr
@@ -295,7 +298,8 @@ def make_runs(only=None):
                         shutil.copy(os.path.join(td, f), os.path.join(dst, f))
             else:
                 p = dict(dim=3, Np=64, density="0.365d0", trap="F", dt="5.0d-3", Nb=40, seed=1982, sampling="bis",
-                         Lstag=16, Nlev=4, Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, a_ho="1.0d0")
+                         Lstag=16, Nlev=4, Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, a_ho="1.0d0",
+                         wf_table="T")
                 p.update(kw)
                 with open(os.path.join(td, "vpi.in"), "w") as f:
                     f.write(VPI_IN.format(**p))

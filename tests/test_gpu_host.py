@@ -65,7 +65,7 @@ def _lbox(src):
 
 
 @pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0", "he4_wormbusy_s7",
-                                  "he4_wormbusy_s8"])
+                                  "he4_wormbusy_s8", "he4_wf_analytic"])
 def test_gpu_front_end_matches_reference_program(exe, name, tmp_path):
     src = os.path.join(RUNS, name)
     _run(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))

@@ -651,3 +651,46 @@ def _trap_batch(rng, S, Paths, n):
     xold = Paths[w, ib, ip - 1].copy()
     xnew = xold + rng.normal(0, 0.3, xold.shape)
     return w, ip, ib, xnew, xold
+
+
+@pytest.mark.parametrize("kw", [dict(dim=3, Np=64, Nb=12), dict(dim=2, Np=20, Nb=8, trap=True, a_ho=[1.0, 1.3])])
+def test_analytic_trial_function_wf_table_false(gpu_lib, oracle, kw):
+    """wf_table = F, the reference's DEFAULT (vpi_mod.f90:59): LogPsi evaluated analytically (McMillan, system_mod.f90:38-66)
+    in UpdateWf (end beads of K1, every kernel variant incl. the reference-order one, which must stay bit-identical) and
+    in LocalEnergy (K4: dudr, d2udr2), against the oracle's wf_table = F branch."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    S = System(wf_table=False, **kw)
+    cfg = SystemConfig(wf_table=False, **kw)
+    VT, WF = oracle.tables(S)
+    rng = np.random.default_rng(5)
+    W = 2
+    if S.trap:
+        Paths = rng.normal(0, 1.2, (W, S.M, S.Np, S.dim))
+        w, ip, ib, xnew, xold = _trap_batch(rng, S, Paths, 26000)
+    else:
+        Paths = _worldlines(oracle, S, W, 5, 0.1)
+        w, ip, ib, xnew, xold = _random_batch(rng, S, Paths, 26000, 0.1)
+    ib[::3] = 0
+    ib[1::3] = 2 * S.Nb                                        # two thirds end beads
+    xold = Paths[w, ib, ip - 1].copy()
+    sel = np.arange(0, len(w), 13)
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w[sel], ip[sel], ib[sel], xnew[sel], xold[sel])
+    fin = np.isfinite(want)
+    with gpu_lib.PigsContext(cfg, VT, None, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        for v in (1, 2, 7, 13, 0, 14):
+            ctx.set_tuning("k1_variant", v)
+            got = ctx.delta_action_batch(w, ip, ib, xnew, xold)[sel] if v in (0, 12) else \
+                ctx.delta_action_batch(w[sel], ip[sel], ib[sel], xnew[sel], xold[sel])
+            assert np.array_equal(np.isnan(got), np.isnan(want)), v
+            if v == 14:
+                assert same_bits(got, want)
+            else:
+                assert np.all(np.abs(got - want)[fin] <= 1e-10 * np.abs(want[fin]) + 1e-10 * np.max(np.abs(want[fin]))), v
+        for slot in (0, 2 * S.Nb):
+            E, K, Pp = ctx.local_energy_batch(slot)
+            for k in range(W):
+                lo = np.array(oracle.local_energy(S, WF, VT, Paths[k][slot]))
+                if np.all(np.isfinite(lo)):
+                    assert _close_rel([E[k], K[k], Pp[k]], lo), (slot, k)
