@@ -14,6 +14,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <unordered_set>
 #include <vector>
 
 #include "pigs_comm.h"
@@ -80,6 +84,15 @@ struct PinBuf {
     void release() { if (h) (void)hipHostFree(h); h = d = nullptr; bytes = 0; }
 };
 
+// several contexts of one process meeting in host memory (pigs_comm_init_all on duplicate devices: rehearsal only)
+struct HostGroup {
+    int n = 0, arrived = 0, generation = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::vector<double>> slot;
+    std::vector<double> sum;
+};
+
 struct pigs_ctx {
     pigs_params hp;
     DevParams   P;
@@ -87,6 +100,8 @@ struct pigs_ctx {
     int         n_walkers = 0;
     hipStream_t stream    = nullptr;
     double *d_paths = nullptr, *d_VT = nullptr, *d_WF = nullptr;
+    std::shared_ptr<HostGroup> hgroup;   // rehearsal form of the estimator reduction (several contexts on one GPU)
+    int hrank = 0;
     double *d_VTimg = nullptr;           // [0, VT(0)] VT(0..Nmax+1) [0 0 0 0]: PipeTab image for the sampler (pigs_k1_device.h)
     size_t  path_doubles = 0;        // resident doubles per walker (padded SoA)
     size_t  raw_doubles  = 0;        // dim*Np*(2Nb+1): reference layout per walker
@@ -117,6 +132,22 @@ static int check_ctx(pigs_ctx *c)
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(PIGS_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
     return PIGS_OK;
+}
+
+// A commit list is a SEQUENCE of assignments Path(:,ip,ib) = x (the caller's program order): when a bead appears more than
+// once the last value must win, as it does in the reference's sequential code.  The kernel writes all entries in
+// parallel, so earlier duplicates are marked here (walker = -1: the kernel skips them).  Found by the sharded front end
+// test: a worm's bead Nb is re-selected (xend(:,1) / xend(:,2)) between half-chain moves and could be queued twice
+// before one flush.
+static void mark_superseded(int64_t n, int32_t *w, const int32_t *ip, const int32_t *ib, int M, int Np)
+{
+    if (n < 2) return;
+    std::unordered_set<uint64_t> seen;
+    seen.reserve((size_t)n * 2);
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const uint64_t key = ((uint64_t)(uint32_t)w[i] * (uint64_t)M + (uint64_t)ib[i]) * (uint64_t)(Np + 1) + (uint64_t)ip[i];
+        if (!seen.insert(key).second) w[i] = -1;
+    }
 }
 
 extern "C" {
@@ -458,6 +489,7 @@ int pigs_commit_staged(pigs_ctx *c, int64_t n)
     for (int64_t i = 0; i < n; ++i)
         if (w[i] < 0 || w[i] >= c->n_walkers || ip[i] < 1 || ip[i] > c->P.Np || ib[i] < 0 || ib[i] >= c->P.M)
             return fail(PIGS_ERR_ARG, "commit %lld: walker=%d ip=%d ib=%d out of range", (long long)i, w[i], ip[i], ib[i]);
+    mark_superseded(n, (int32_t *)c->cs_w.h, ip, ib, c->P.M, c->P.Np);
     HIPCHK(launch_commit_beads(c->P, c->d_paths, n, (const int32_t *)c->cs_w.d, (const int32_t *)c->cs_ip.d,
                                (const int32_t *)c->cs_ib.d, (const double *)c->cs_x.d, c->stream));
     return PIGS_OK;
@@ -475,7 +507,9 @@ int pigs_commit_beads(pigs_ctx *c, int64_t n, const int32_t *walker, const int32
     HIPCHK(c->d_walker.reserve(n)); HIPCHK(c->d_ip.reserve(n)); HIPCHK(c->d_ib.reserve(n));
     HIPCHK(c->d_xnew.reserve(nd));
     hipStream_t s = c->stream;
-    HIPCHK(hipMemcpyAsync(c->d_walker.p, walker, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    std::vector<int32_t> wl(walker, walker + n);
+    mark_superseded(n, wl.data(), ip, ib, c->P.M, c->P.Np);
+    HIPCHK(hipMemcpyAsync(c->d_walker.p, wl.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_ip.p, ip, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xnew.p, x, nd * sizeof(double), hipMemcpyHostToDevice, s));
@@ -871,16 +905,29 @@ int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks)
     if (!ctxs || nranks < 1) return fail(PIGS_ERR_ARG, "bad arguments");
     std::vector<int> devs(nranks);
     std::vector<pigs_comm *> comms(nranks, nullptr);
+    bool distinct = true;
     for (int i = 0; i < nranks; ++i) {
         if (!ctxs[i]) return fail(PIGS_ERR_ARG, "null context %d", i);
         devs[i] = ctxs[i]->device;
+        for (int k = 0; k < i; ++k) distinct = distinct && devs[k] != devs[i];
+    }
+    for (int i = 0; i < nranks; ++i) {
+        if (ctxs[i]->comm) { pigs_comm_destroy(ctxs[i]->comm); ctxs[i]->comm = nullptr; }
+        ctxs[i]->hgroup.reset();
+    }
+    if (!distinct) {
+        // REHEARSAL form (several contexts on one GPU, e.g. a one-GPU test box: RCCL wants one device per rank): the
+        // vectors meet in host memory, every rank adds the ranks' vectors in rank order (deterministic).  Not a
+        // multi-GPU path: the product form is the RCCL communicator below.
+        auto g = std::make_shared<HostGroup>();
+        g->n = nranks;
+        g->slot.resize(nranks);
+        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; }
+        return PIGS_OK;
     }
     const char *err = pigs_comm_create_all(comms.data(), nranks, devs.data());
     if (err) return fail(PIGS_ERR_COMM, "%s", err);
-    for (int i = 0; i < nranks; ++i) {
-        if (ctxs[i]->comm) pigs_comm_destroy(ctxs[i]->comm);
-        ctxs[i]->comm = comms[i];
-    }
+    for (int i = 0; i < nranks; ++i) ctxs[i]->comm = comms[i];
     return PIGS_OK;
 }
 
@@ -889,6 +936,27 @@ int pigs_estimators_allreduce(pigs_ctx *c, double *vec, int32_t n)
     int rc = check_ctx(c); if (rc) return rc;
     if (n < 0 || (n && !vec)) return fail(PIGS_ERR_ARG, "bad vector");
     if (n == 0) return PIGS_OK;
+    if (c->hgroup) {
+        HostGroup &g = *c->hgroup;
+        std::unique_lock<std::mutex> lk(g.m);
+        g.slot[c->hrank].assign(vec, vec + n);
+        const int gen = g.generation;
+        if (++g.arrived == g.n) {
+            g.sum.assign(n, 0.0);
+            for (int r = 0; r < g.n; ++r) {
+                if ((int)g.slot[r].size() != n) { g.arrived = 0; ++g.generation; g.cv.notify_all(); return fail(PIGS_ERR_ARG, "ranks disagree on the vector length"); }
+                for (int k = 0; k < n; ++k) g.sum[k] += g.slot[r][k];
+            }
+            g.arrived = 0;
+            ++g.generation;
+            g.cv.notify_all();
+        } else {
+            g.cv.wait(lk, [&] { return g.generation != gen; });
+        }
+        if ((int)g.sum.size() != n) return fail(PIGS_ERR_ARG, "ranks disagree on the vector length");
+        memcpy(vec, g.sum.data(), (size_t)n * sizeof(double));
+        return PIGS_OK;
+    }
     if (!c->comm) return fail(PIGS_ERR_COMM, "no communicator: call pigs_comm_init_rank / pigs_comm_init_all first");
     HIPCHK(c->d_res.reserve(n));
     hipStream_t s = c->stream;

@@ -417,6 +417,7 @@ __global__ void k_commit_beads(DevParams P, double *__restrict__ paths, int64_t 
     if (t >= n * P.dim) return;
     const int64_t i = t / P.dim;
     const int k = (int)(t - i * P.dim);
+    if (walker[i] < 0) return;                       // superseded by a later entry for the same bead (mark_superseded)
     const size_t sl = slice_doubles(P.dim, P.NpPad);
     paths[((size_t)walker[i] * P.M + ibv[i]) * sl + (size_t)k * P.NpPad + (ipv[i] - 1)] = x[t];
 }

@@ -6,7 +6,11 @@
 ! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
 ! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
 ! system_mod.f90:15-34) plus one optional group of its own,
-!     &gpu  n_walkers = 1, device = 0, device_sampler = F, potential = 'aziz2', k1_variant = 0  /
+!     &gpu  n_walkers = 1, device = 0, n_gpus = 1, device_sampler = F, potential = 'aziz2', k1_variant = 0  /
+! (n_gpus = G: the walkers are sharded in contiguous blocks over G GPUs -- devices device .. device+G-1, one
+! context and one OpenMP host thread per GPU, no exchange while sampling -- and the block estimators of the shards
+! meet ONCE per block in one all-reduce (RCCL over xGMI: pigs_comm_init_all / pigs_estimators_allreduce); thread 0
+! writes the walker-summed files.  same_device = T puts every shard on `device`: a one-GPU rehearsal.)
 ! (potential: aziz2 | lj | dipolar -- the reference selects it by editing system_mod.f90)
 ! (device_sampler = T: the whole MC step runs on the GPU, kernel K6 -- diagonal sector with
 ! sampling='bis' and CWorm = 0 only; otherwise the host-driven lock-step sampler is used)
@@ -26,6 +30,7 @@ program pigs_vpi
   use pigs_rng
   use pigs_sampler
   use pigs_estimators
+  use omp_lib
 
   implicit none
 
@@ -35,9 +40,8 @@ program pigs_vpi
   real (kind=8)     :: density,dt,delta_cm,CWorm,Rm
   real (kind=8)     :: a_ho(3)
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
-  integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios,k1_variant
-  logical           :: device_sampler,checkpointing
-  integer(c_int32_t) :: rpos
+  integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios,k1_variant,n_gpus
+  logical           :: device_sampler,checkpointing,same_device
   character (len=8) :: potential
   integer           :: pot_kind
   namelist /system/  dim,Np,density,crystal,trap
@@ -46,43 +50,18 @@ program pigs_vpi
   namelist /wavefun/ Nmax,wf_table,v_table
   namelist /extpot/  a_ho
   namelist /jastrow/ Rm
-  namelist /gpu/     n_walkers,device,device_sampler,potential,checkpointing,k1_variant
+  namelist /gpu/     n_walkers,device,device_sampler,potential,checkpointing,k1_variant,n_gpus,same_device
 
-  type(sampler_t)    :: s
-  type(est_params)   :: ep
+
+  ! shared by the shards (read-only once the parallel region starts)
   type(pigs_params)  :: gp
-  type(c_ptr)        :: ctx
-  type(perm_state), allocatable :: perm(:)
-
+  type(c_ptr), allocatable :: ctxs(:)
+  integer, allocatable :: lo(:),hi(:)
   real(8) :: Lbox(3),rcut,rcut2,rbin,dr,pi
   real(8), allocatable :: VTable(:),LogWF(:)
-  integer :: NW,w,k,ip,ib,istep,iblock,istag,iobdm,j,nd,i
-  integer, allocatable :: ipv(:),iupd(:),partner(:),diag_list(:)
-  logical, allocatable :: act(:),isopen0(:),swp(:)
-  integer(c_int32_t), allocatable :: wl(:)
-  real(8), allocatable :: E1(:),E2(:),K1(:),P1(:),Et(:),Kt(:),Pt(:)
-  real(8) :: E,Kin,Pot
-
-  ! per-walker counters and accumulators (one column per walker)
-  integer, allocatable :: acc_cm(:),acc_bd(:),acc_head(:),acc_tail(:),acc_cm_half(:),acc_bd_half(:)
-  integer, allocatable :: acc_head_half(:),acc_tail_half(:),acc_open(:),acc_close(:),acc_swap(:)
-  integer, allocatable :: try_open(:),try_close(:),try_swap(:)
-  real(8), allocatable :: try_cm(:),try_stag(:),try_cm_half(:),try_stag_half(:)
-  integer, allocatable :: idiag(:),idiag_aux(:),idiag_block(:),obdm_bl(:),diag_bl(:),ngr(:)
-  real(8), allocatable :: BE(:,:),BE2(:,:),BT(:,:),BT2(:,:),AE(:,:),AE2(:,:),AT(:,:),AT2(:,:)
-  real(8), allocatable :: gr(:,:),AvGr(:,:),AvGr2(:,:),Sk(:,:,:),AvSk(:,:,:),AvSk2(:,:,:)
-  real(8), allocatable :: nrho(:,:,:),AvNr(:,:,:),AvNr2(:,:,:)
-  real(8) :: t0,t1,mE(3),mT(3)
-  integer, allocatable :: ue(:),ut(:),uh(:)
-  integer :: ueav,utav,ucfg
-  logical :: lflag
-  integer(8) :: c0,c1,crate
-  type(pigs_sweep_params) :: swp_par
-  real(8), allocatable :: gr_inc(:,:),sk_inc(:,:,:)
-  integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
-  integer(c_int32_t), allocatable :: dev_open(:),dev_iworm(:),dev_ev(:,:),dev_reset(:)
-  real(8), allocatable :: dev_nrho(:,:,:)
-  character(len=32) :: suffix
+  integer :: NWtot,G,ish0,k,ucfg0
+  real(8), allocatable :: chk_all(:,:,:,:),AE_all(:,:),AT_all(:,:)
+  integer, allocatable :: diag_bl_all(:)
 
   !---------------------------------------------------------------------
   ! defaults (reference vpi_mod.f90:39-60) and input
@@ -93,6 +72,7 @@ program pigs_vpi
   CMFreq = 1; Nstag = 1; Nblock = 1; Nstep = 1; Nbin = 100; Nk = 50; sampling = 'bis'
   delta_cm = 0.d0; density = 0.d0; a_ho = 1.d0; Rm = 1.d0
   n_walkers = 1; device = 0; device_sampler = .false.; potential = 'aziz2'; checkpointing = .true.; k1_variant = 0
+  n_gpus = 1; same_device = .false.
 
   read (5,nml=system,iostat=ios);  rewind (5)
   read (5,nml=samp,iostat=ios);    rewind (5)
@@ -108,7 +88,8 @@ program pigs_vpi
      write (0,*) 'pigs_vpi: v_table = T is required (the reference Force() is a stub: system_mod.f90:186-209)'
      stop 2
   end if
-  NW  = n_walkers
+  NWtot = n_walkers
+  G = max(1,min(n_gpus,NWtot))
   pi = acos(-1.d0)
   if (device_sampler .and. Lstag>Nb .and. CWorm>0.d0) then
      write (0,*) 'pigs_vpi: device_sampler = T with CWorm > 0 needs Lstag <= Nb (half-chain moves); using the host-driven sampler'
@@ -129,11 +110,11 @@ program pigs_vpi
   else
      if (crystal) then
         ! lattice start: particle number, box and density come from config_ini.in (reference vpi.f90:99-107)
-        open (newunit=ucfg,file='config_ini.in',status='old')
-        read (ucfg,*) Np
-        read (ucfg,*) (Lbox(k),k=1,dim)
-        read (ucfg,*) density
-        close (ucfg)
+        open (newunit=ucfg0,file='config_ini.in',status='old')
+        read (ucfg0,*) Np
+        read (ucfg0,*) (Lbox(k),k=1,dim)
+        read (ucfg0,*) density
+        close (ucfg0)
      else
         do k=1,dim
            Lbox(k) = (real(Np)/density)**(1.d0/real(dim))
@@ -162,9 +143,107 @@ program pigs_vpi
   gp%trap = merge(1,0,trap); gp%wf_table = merge(1,0,wf_table); gp%v_table = 1; gp%reserved = 0
   gp%dr = dr; gp%rcut2 = rcut2; gp%dt = dt; gp%Rm = Rm
   gp%Lbox = Lbox; gp%a_ho = a_ho
-  call pigs_check(pigs_ctx_create(gp,VTable,LogWF,int(NW,c_int32_t),int(device,c_int32_t),ctx),'pigs_ctx_create')
-  ! k1_variant = 2 selects the Delta-S kernel that keeps the reference's rounding of every term (default 0: short arithmetic)
-  if (k1_variant/=0) call pigs_check(pigs_set_tuning(ctx,'k1_variant'//c_null_char,int(k1_variant,c_int32_t)),'pigs_set_tuning')
+  ! one context per GPU, each with a contiguous block of walkers (sharding.shard_walkers: the first mod(NW,G) shards
+  ! get one walker more); walker w (global, 1-based) runs the chain of seed+w-1 whatever the partition
+  allocate (ctxs(G),lo(G),hi(G))
+  do ish0=1,G
+     lo(ish0) = (ish0-1)*(NWtot/G)+min(ish0-1,mod(NWtot,G))+1
+     hi(ish0) = lo(ish0)+NWtot/G-1
+     if (ish0<=mod(NWtot,G)) hi(ish0) = hi(ish0)+1
+     call pigs_check(pigs_ctx_create(gp,VTable,LogWF,int(hi(ish0)-lo(ish0)+1,c_int32_t), &
+          & int(merge(device,device+ish0-1,same_device),c_int32_t),ctxs(ish0)),'pigs_ctx_create')
+     ! k1_variant = 2 selects the Delta-S kernel that keeps the reference's rounding of every term (default 0: short arithmetic)
+     if (k1_variant/=0) call pigs_check(pigs_set_tuning(ctxs(ish0),'k1_variant'//c_null_char,int(k1_variant,c_int32_t)), &
+          & 'pigs_set_tuning')
+  end do
+  if (G>1) call pigs_check(pigs_comm_init_all(ctxs,int(G,c_int32_t)),'pigs_comm_init_all')
+  allocate (chk_all(dim,Np,0:2*Nb,NWtot),AE_all(3,NWtot),AT_all(3,NWtot),diag_bl_all(NWtot))
+  diag_bl_all = 0
+
+  print '(a)',       ' =============================================================='
+  print '(a)',       '            VPI Monte Carlo on MI355X (pigs_vpi)               '
+  print '(a)',       ' =============================================================='
+  print '(a,i6)',    '  > Walkers (lock-step) :',NWtot
+  print '(a,i6)',    '  > GPUs (walker shards):',G
+  print '(a,i6)',    '  > Dimensions          :',dim
+  print '(a,i6)',    '  > Number of particles :',Np
+  print '(a,i6)',    '  > Number of beads     :',Nb
+  print '(a,g13.6)', '  > Time step           :',dt
+  print '(a,i6)',    '  > Number of blocks    :',Nblock
+  print '(a,i6)',    '  > MC steps per block  :',Nstep
+
+  !=====================================================================
+
+  !$omp parallel num_threads(G) default(shared)
+  call run_shard(omp_get_thread_num()+1)
+  !$omp end parallel
+
+  print '(a)', ' =============================================================='
+  print '(a)', ' FINAL RESULTS (per walker: <E> <Ec> <Ep> | <Et> <Kt> <Vt>, per particle)'
+  do k=1,NWtot
+     if (diag_bl_all(k)>0) print '(i6,6g16.8)', k-1,AE_all(:,k)/real(diag_bl_all(k))/Np,AT_all(:,k)/real(diag_bl_all(k))/Np
+  end do
+  print '(a)', ' =============================================================='
+  open (newunit=k,file='worldlines_final.bin',form='unformatted',access='stream')
+  write (k) chk_all
+  close (k)
+  do ish0=1,G
+     call pigs_check(pigs_ctx_destroy(ctxs(ish0)),'pigs_ctx_destroy')
+  end do
+
+contains
+
+  !---------------------------------------------------------------------
+  ! one shard: the walkers lo(ish)..hi(ish) on context ctxs(ish), the reference's block / step structure
+  ! (vpi.f90:244-588) for all of them in lock-step.  Everything below is private to the calling thread.
+  subroutine run_shard(ish)
+  integer, intent(in) :: ish
+  integer(c_int32_t) :: rpos
+  integer :: NW,w0
+  logical :: trace
+  character(len=8) :: envbuf
+
+  type(sampler_t)    :: s
+  type(est_params)   :: ep
+  type(c_ptr)        :: ctx
+  type(perm_state), allocatable :: perm(:)
+
+  integer :: w,k,ip,ib,istep,iblock,istag,iobdm,j,nd,i,nvec,ndall,ngrall,nnrall,ngrav,nnrav
+  integer, allocatable :: ipv(:),iupd(:),partner(:),diag_list(:)
+  logical, allocatable :: act(:),isopen0(:),swp(:)
+  integer(c_int32_t), allocatable :: wl(:)
+  real(8), allocatable :: E1(:),E2(:),K1(:),P1(:),Et(:),Kt(:),Pt(:)
+  real(8) :: E,Kin,Pot
+
+  ! per-walker counters and accumulators (one column per walker)
+  integer, allocatable :: acc_cm(:),acc_bd(:),acc_head(:),acc_tail(:),acc_cm_half(:),acc_bd_half(:)
+  integer, allocatable :: acc_head_half(:),acc_tail_half(:),acc_open(:),acc_close(:),acc_swap(:)
+  integer, allocatable :: try_open(:),try_close(:),try_swap(:)
+  real(8), allocatable :: try_cm(:),try_stag(:),try_cm_half(:),try_stag_half(:)
+  integer, allocatable :: idiag(:),idiag_aux(:),idiag_block(:),obdm_bl(:),diag_bl(:),ngr(:)
+  real(8), allocatable :: BE(:,:),BE2(:,:),BT(:,:),BT2(:,:),AE(:,:),AE2(:,:),AT(:,:),AT2(:,:)
+  real(8), allocatable :: gr(:,:),AvGr(:,:),AvGr2(:,:),Sk(:,:,:),AvSk(:,:,:),AvSk2(:,:,:)
+  real(8), allocatable :: nrho(:,:,:),AvNr(:,:,:),AvNr2(:,:,:)
+  real(8) :: t0,t1,mE(3),mT(3)
+  integer, allocatable :: ue(:),ut(:),uh(:)
+  integer :: ueav,utav,ucfg
+  logical :: lflag
+  integer(8) :: c0,c1,crate
+  type(pigs_sweep_params) :: swp_par
+  real(8), allocatable :: gr_inc(:,:),sk_inc(:,:,:)
+  integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
+  integer(c_int32_t), allocatable :: dev_open(:),dev_iworm(:),dev_ev(:,:),dev_reset(:)
+  real(8), allocatable :: dev_nrho(:,:,:)
+  character(len=32) :: suffix
+
+  real(8), allocatable :: vec(:),AvGrAll(:),AvGr2All(:),AvSkAll(:,:),AvSk2All(:,:),AvNrAll(:,:),AvNr2All(:,:),tmp1(:),tmp2(:,:),tmp3(:,:)
+  real(8) :: cnt_all(13)
+
+  call get_environment_variable('PIGS_VPI_TRACE',envbuf)
+  trace = envbuf(1:1)=='1'
+  NW  = hi(ish)-lo(ish)+1
+  w0  = lo(ish)-1                        ! global walker index = w0 + local index
+  ctx = ctxs(ish)
 
   call sampler_init(s,dim,Np,Nb,NW,trap,dt,density,CWorm,Lbox(1:dim),ctx)
   ep%dim = dim; ep%Np = Np; ep%Nbin = Nbin; ep%Nk = Nk; ep%Npw = Npw; ep%trap = trap
@@ -176,7 +255,7 @@ program pigs_vpi
   ! point; walker w seeds its stream with seed+w-1
   do w=1,NW
      suffix = ''
-     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     if (NWtot>1) write (suffix,'(a,i4.4)') '.w',w0+w-1
      if (resume) then
         open (newunit=ucfg,file='checkpoint'//trim(suffix)//'.dat',status='old')
         read (ucfg,*) lflag                      ! trap: the reference's init takes it from the file (vpi_mod.f90:166);
@@ -202,7 +281,7 @@ program pigs_vpi
         call mt_load(s%rng(w),'rand_state'//trim(suffix))
         cycle
      end if
-     call mt_seed(s%rng(w),seed+w-1)
+     call mt_seed(s%rng(w),seed+w0+w-1)
      if (crystal .and. .not. trap) then
         open (newunit=ucfg,file='config_ini.in',status='old')
         read (ucfg,*)
@@ -270,28 +349,24 @@ program pigs_vpi
   allocate (ue(NW),ut(NW),uh(NW))
   do w=1,NW
      suffix = ''
-     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     if (NWtot>1) write (suffix,'(a,i4.4)') '.w',w0+w-1
      open (newunit=ue(w),file='e_vpi'//trim(suffix)//'.out')
      open (newunit=ut(w),file='et_vpi'//trim(suffix)//'.out')
      open (newunit=uh(w),file='e_vpi'//trim(suffix)//'.hex')
   end do
-  if (NW>1) then
+  if (NWtot>1 .and. ish==1) then
      open (newunit=ueav,file='e_vpi.out')
      open (newunit=utav,file='et_vpi.out')
   end if
 
-  print '(a)',       ' =============================================================='
-  print '(a)',       '            VPI Monte Carlo on MI355X (pigs_vpi)               '
-  print '(a)',       ' =============================================================='
-  print '(a,i6)',    '  > Walkers (lock-step) :',NW
-  print '(a,i6)',    '  > Dimensions          :',dim
-  print '(a,i6)',    '  > Number of particles :',Np
-  print '(a,i6)',    '  > Number of beads     :',Nb
-  print '(a,g13.6)', '  > Time step           :',dt
-  print '(a,i6)',    '  > Number of blocks    :',Nblock
-  print '(a,i6)',    '  > MC steps per block  :',Nstep
+  ! the vector that meets the other shards' once per block: number of walkers with a diagonal block, their summed block
+  ! energies, the block's counters, the summed normalised g(r), S(k), n(r) and how many walkers contributed to each
+  nvec = 7+13+Nbin+dim*Nk+(Npw+1)*Nbin+2
+  allocate (vec(nvec),AvGrAll(Nbin),AvGr2All(Nbin),AvSkAll(dim,Nk),AvSk2All(dim,Nk),AvNrAll(0:Npw,Nbin),AvNr2All(0:Npw,Nbin))
+  allocate (tmp1(Nbin),tmp2(dim,Nk),tmp3(0:Npw,Nbin))
+  AvGrAll = 0.d0; AvGr2All = 0.d0; AvSkAll = 0.d0; AvSk2All = 0.d0; AvNrAll = 0.d0; AvNr2All = 0.d0
+  ngrav = 0; nnrav = 0
 
-  !=====================================================================
   do iblock=1,Nblock
 
      call system_clock(c0,crate)
@@ -417,6 +492,9 @@ program pigs_vpi
         end if
 
         end if   ! host-driven / device-resident sampler
+        if (trace .and. .not. device_sampler) then       ! PIGS_VPI_TRACE=1: one checksum per walker and step (debugging aid)
+           print '(a,2i6,*(1x,z16.16))', ' trace',iblock,istep,(transfer(sum(s%Path(:,:,:,w)),1_8),w=1,NW)
+        end if
 
         ! ---- estimators of the walkers in the diagonal sector (reference vpi.f90:406-473)
         nd = 0
@@ -486,6 +564,7 @@ program pigs_vpi
         end if
      end if
      mE = 0.d0; mT = 0.d0; nd = 0
+     vec = 0.d0
      do w=1,NW
         if (idiag_block(w)/=0) then
            BE(:,w)  = BE(:,w)/real(idiag_block(w));  BE2(:,w) = BE2(:,w)/real(idiag_block(w))
@@ -498,6 +577,9 @@ program pigs_vpi
               call normalize_sk(ep,ngr(w),Sk(:,:,w))
               AvGr(:,w) = AvGr(:,w)+gr(:,w); AvGr2(:,w) = AvGr2(:,w)+gr(:,w)*gr(:,w)
               AvSk(:,:,w) = AvSk(:,:,w)+Sk(:,:,w); AvSk2(:,:,w) = AvSk2(:,:,w)+Sk(:,:,w)*Sk(:,:,w)
+              vec(21:20+Nbin) = vec(21:20+Nbin)+gr(:,w)
+              vec(21+Nbin:20+Nbin+dim*Nk) = vec(21+Nbin:20+Nbin+dim*Nk)+reshape(Sk(:,:,w),[dim*Nk])
+              vec(nvec-1) = vec(nvec-1)+1.d0
            end if
            write (ue(w),'(5g20.10e3)') real(iblock),BE(1,w)/Np,BE(2,w)/Np,BE(3,w)/Np
            write (ut(w),'(5g20.10e3)') real(iblock),BT(1,w)/Np,BT(2,w)/Np,BT(3,w)/Np
@@ -509,14 +591,39 @@ program pigs_vpi
            if (.not. trap) then
               call normalize_nr(ep,density,real(idiag_aux(w),8),Nobdm,nrho(:,:,w))
               AvNr(:,:,w) = AvNr(:,:,w)+nrho(:,:,w); AvNr2(:,:,w) = AvNr2(:,:,w)+nrho(:,:,w)*nrho(:,:,w)
+              vec(21+Nbin+dim*Nk:20+Nbin+dim*Nk+(Npw+1)*Nbin) = vec(21+Nbin+dim*Nk:20+Nbin+dim*Nk+(Npw+1)*Nbin) &
+                   & +reshape(nrho(:,:,w),[(Npw+1)*Nbin])
+              vec(nvec) = vec(nvec)+1.d0
            end if
            idiag_aux(w) = 0
            nrho(:,:,w)  = 0.d0
         end if
      end do
-     if (NW>1 .and. nd>0) then
-        write (ueav,'(5g20.10e3)') real(iblock),mE/nd
-        write (utav,'(5g20.10e3)') real(iblock),mT/nd
+     ! ---- the block's one exchange between the shards: all-reduce of the estimator vector
+     vec(1) = nd; vec(2:4) = mE; vec(5:7) = mT
+     vec(8:20) = [dble(sum(acc_cm)),sum(try_cm),dble(sum(acc_bd)),dble(sum(acc_head)),dble(sum(acc_tail)),sum(try_stag), &
+          & dble(sum(idiag_block)),dble(sum(acc_open)),dble(sum(try_open)),dble(sum(acc_close)),dble(sum(try_close)), &
+          & dble(sum(acc_swap)),dble(sum(try_swap))]
+     if (G>1) call pigs_check(pigs_estimators_allreduce(ctx,vec,int(nvec,c_int32_t)),'pigs_estimators_allreduce')
+     ndall = nint(vec(1)); mE = vec(2:4); mT = vec(5:7); cnt_all = vec(8:20)
+     ngrall = nint(vec(nvec-1)); nnrall = nint(vec(nvec))
+     if (ish==1 .and. NWtot>1) then
+        if (ndall>0) then
+           write (ueav,'(5g20.10e3)') real(iblock),mE/ndall
+           write (utav,'(5g20.10e3)') real(iblock),mT/ndall
+        end if
+        if (ngrall>0) then                   ! walker average of the block's normalised g(r), S(k)
+           ngrav = ngrav+1
+           tmp1 = vec(21:20+Nbin)/ngrall
+           tmp2 = reshape(vec(21+Nbin:20+Nbin+dim*Nk),[dim,Nk])/ngrall
+           AvGrAll = AvGrAll+tmp1; AvGr2All = AvGr2All+tmp1*tmp1
+           AvSkAll = AvSkAll+tmp2; AvSk2All = AvSk2All+tmp2*tmp2
+        end if
+        if (nnrall>0) then
+           nnrav = nnrav+1
+           tmp3 = reshape(vec(21+Nbin+dim*Nk:20+Nbin+dim*Nk+(Npw+1)*Nbin),[Npw+1,Nbin])/nnrall
+           AvNrAll = AvNrAll+tmp3; AvNr2All = AvNr2All+tmp3*tmp3
+        end if
      end if
      ! ---- checkpoint (reference vpi.f90:541-545, vpi_mod.f90:263-309): text worldline, particle-major
      if (checkpointing) then
@@ -531,7 +638,7 @@ program pigs_vpi
         end if
         do w=1,NW
            suffix = ''
-           if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+           if (NWtot>1) write (suffix,'(a,i4.4)') '.w',w0+w-1
            open (newunit=ucfg,file='checkpoint'//trim(suffix)//'.dat')
            if (trap) then
               write (ucfg,*) ".True."
@@ -561,22 +668,24 @@ program pigs_vpi
      call system_clock(c1)
      t0 = 0.d0; t1 = dble(c1-c0)/dble(crate)
 
+     if (ish==1) then
      print '(a)',            ' -----------------------------------------------------------'
      print '(a,i8)',         ' BLOCK NUMBER :',iblock
-     if (nd>0) then
-        print '(a,3g18.9)',  '   > <E>,<Ec>,<Ep>  =',mE/nd
-        print '(a,3g18.9)',  '   > <Et>,<Kt>,<Vt> =',mT/nd
+     if (ndall>0) then
+        print '(a,3g18.9)',  '   > <E>,<Ec>,<Ep>  =',mE/ndall
+        print '(a,3g18.9)',  '   > <Et>,<Kt>,<Vt> =',mT/ndall
      end if
-     print '(a,f7.2,a)',     '   > CM movements      =',100*real(sum(acc_cm))/max(sum(try_cm),1.d0),' %'
-     print '(a,f7.2,a)',     '   > Staging movements =',100*real(sum(acc_bd))/max(sum(try_stag),1.d0),' %'
-     print '(a,f7.2,a)',     '   > Head movements    =',100*real(sum(acc_head))/max(sum(try_stag),1.d0),' %'
-     print '(a,f7.2,a)',     '   > Tail movements    =',100*real(sum(acc_tail))/max(sum(try_stag),1.d0),' %'
-     print '(a,f7.2,a)',     '   > Diagonal conf.    =',100.d0*real(sum(idiag_block))/real(Nstep*NW),' %'
-     print '(a,f7.2,a)',     '   > Open acc          =',100.d0*real(sum(acc_open))/max(real(sum(try_open)),1.0),' %'
-     print '(a,f7.2,a)',     '   > Close acc         =',100.d0*real(sum(acc_close))/max(real(sum(try_close)),1.0),' %'
-     print '(a,f7.2,a)',     '   > Swap acc          =',100.d0*real(sum(acc_swap))/max(real(sum(try_swap)),1.0),' %'
-     print '(a,f9.2,a,i12,a,i10,a,f9.2,a)', '   > Time per block    =',t1-t0,' s;  Delta S items so far',s%n_eval_items, &
+     print '(a,f7.2,a)',     '   > CM movements      =',100*cnt_all(1)/max(cnt_all(2),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Staging movements =',100*cnt_all(3)/max(cnt_all(6),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Head movements    =',100*cnt_all(4)/max(cnt_all(6),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Tail movements    =',100*cnt_all(5)/max(cnt_all(6),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Diagonal conf.    =',100.d0*cnt_all(7)/real(Nstep*NWtot),' %'
+     print '(a,f7.2,a)',     '   > Open acc          =',100.d0*cnt_all(8)/max(cnt_all(9),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Close acc         =',100.d0*cnt_all(10)/max(cnt_all(11),1.d0),' %'
+     print '(a,f7.2,a)',     '   > Swap acc          =',100.d0*cnt_all(12)/max(cnt_all(13),1.d0),' %'
+     print '(a,f9.2,a,i12,a,i10,a,f9.2,a)', '   > Time per block    =',t1-t0,' s;  Delta S items so far (shard 1)',s%n_eval_items, &
           & ' in',s%n_eval_calls,' batches,',s%t_eval,' s inside them'
+     end if
 
   end do   ! iblock
 
@@ -584,7 +693,7 @@ program pigs_vpi
   ! final averages and files (reference vpi.f90:590-642)
   do w=1,NW
      suffix = ''
-     if (NW>1) write (suffix,'(a,i4.4)') '.w',w-1
+     if (NWtot>1) write (suffix,'(a,i4.4)') '.w',w0+w-1
      close (ue(w)); close (ut(w)); close (uh(w))
      if (swapping) then
         open (newunit=k,file='perm_vpi'//trim(suffix)//'.out')
@@ -601,16 +710,18 @@ program pigs_vpi
         call write_nr('nr_vpi'//trim(suffix)//'.out',ep,obdm_bl(w),AvNr(:,:,w),AvNr2(:,:,w))
      end if
   end do
-  if (NW>1) then
+  if (NWtot>1 .and. ish==1) then
      close (ueav); close (utav)
+     if (.not. trap) then                    ! walker-averaged histograms from the reduced block vectors
+        call write_radial('gr_vpi.out',ep,ngrav,AvGrAll,AvGr2All)
+        call write_sk('sk_vpi.out',ep,ngrav,AvSkAll,AvSk2All)
+        call write_nr('nr_vpi.out',ep,nnrav,AvNrAll,AvNr2All)
+     end if
   end if
 
-  print '(a)', ' =============================================================='
-  print '(a)', ' FINAL RESULTS (per walker: <E> <Ec> <Ep> | <Et> <Kt> <Vt>, per particle)'
   do w=1,NW
-     if (diag_bl(w)>0) print '(i6,6g16.8)', w-1,AE(:,w)/real(diag_bl(w))/Np,AT(:,w)/real(diag_bl(w))/Np
+     AE_all(:,w0+w) = AE(:,w); AT_all(:,w0+w) = AT(:,w); diag_bl_all(w0+w) = diag_bl(w)
   end do
-  print '(a)', ' =============================================================='
 
   ! final worldlines back from the device must equal the host mirror: the two were kept in
   ! step by commits only
@@ -624,12 +735,10 @@ program pigs_vpi
        write (0,*) 'pigs_vpi: device worldlines differ from the host mirror'
        stop 3
     end if
-    open (newunit=k,file='worldlines_final.bin',form='unformatted',access='stream')
-    write (k) chk
-    close (k)
+    chk_all(:,:,:,w0+1:w0+NW) = chk
   end block
 
   call sampler_free(s)
-  call pigs_check(pigs_ctx_destroy(ctx),'pigs_ctx_destroy')
+  end subroutine run_shard
 
 end program pigs_vpi

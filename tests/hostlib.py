@@ -19,7 +19,7 @@ def build_cpu_host():
     shim = os.path.join(BUILD, "libpigs_cpu_shim.so")
     srcs = [os.path.join(ROOT, "tests", "shim", "pigs_cpu_shim.c"), os.path.join(ROOT, "oracle", "pigs_oracle.c")]
     if not os.path.exists(shim) or any(os.path.getmtime(s) > os.path.getmtime(shim) for s in srcs):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-shared", "-o", shim] + srcs + ["-lm"])
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-ffp-contract=off", "-shared", "-pthread", "-o", shim] + srcs + ["-lm"])
     subprocess.check_call(["make", "-s", "-B", "-C", HOST, f"OUT={BUILD}", "OBJ=/tmp/pigs_host_obj_cpu",
                            f"BACKEND_DIR={BUILD}", "BACKEND=pigs_cpu_shim", "all"])
     return shim, os.path.join(BUILD, "libpigs_host.so"), os.path.join(BUILD, "pigs_vpi")

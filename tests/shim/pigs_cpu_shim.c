@@ -6,6 +6,7 @@
  * It is not a fallback: the product library libpigs_hip.so has no CPU path, and nothing
  * outside tests/ links this file.  Parity claims for the kernels never rest on it.      */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +24,8 @@ struct pigs_ctx {
     int32_t *st_w, *st_ip, *st_ib, *cs_w, *cs_ip, *cs_ib;
     double  *st_xn, *st_xo, *st_out, *cs_x;
     int64_t st_cap, cs_cap;
+    void   *group;     /* shim_group of pigs_comm_init_all */
+    int     grank;
 };
 
 static char g_err[256] = "";
@@ -229,6 +232,53 @@ int pigs_structure_batch(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t ib, 
 
 int pigs_comm_unique_id(char id[128]) { memset(id, 0, 128); return PIGS_OK; }
 int pigs_comm_init_rank(pigs_ctx *c, int32_t n, int32_t r, const char id[128]) { (void)c; (void)n; (void)r; (void)id; return PIGS_OK; }
-int pigs_comm_init_all(pigs_ctx **c, int32_t n) { (void)c; (void)n; return PIGS_OK; }
-int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n) { (void)c; (void)v; (void)n; return PIGS_OK; }
+/* several contexts of one process (the front end's &gpu n_gpus > 1: one host thread per context): the vectors meet in
+ * host memory and every rank adds them in rank order -- what RCCL does between GPUs */
+typedef struct shim_group {
+    int n, arrived, generation, len;
+    pthread_mutex_t m;
+    pthread_cond_t cv;
+    double *slot, *sum;
+} shim_group;
+
+int pigs_comm_init_all(pigs_ctx **c, int32_t n)
+{
+    if (!c || n < 1) return PIGS_ERR_ARG;
+    shim_group *g = (shim_group *)calloc(1, sizeof *g);
+    g->n = n;
+    pthread_mutex_init(&g->m, NULL);
+    pthread_cond_init(&g->cv, NULL);
+    for (int i = 0; i < n; ++i) { c[i]->group = g; c[i]->grank = i; }
+    return PIGS_OK;
+}
+
+int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n)
+{
+    if (!c || !v || n < 0) return PIGS_ERR_ARG;
+    shim_group *g = (shim_group *)c->group;
+    if (!g || g->n == 1) return PIGS_OK;
+    pthread_mutex_lock(&g->m);
+    if (g->len < n) {
+        g->slot = (double *)realloc(g->slot, (size_t)g->n * n * sizeof(double));
+        g->sum  = (double *)realloc(g->sum, (size_t)n * sizeof(double));
+        g->len = n;
+    }
+    memcpy(g->slot + (size_t)c->grank * n, v, (size_t)n * sizeof(double));
+    const int gen = g->generation;
+    if (++g->arrived == g->n) {
+        for (int k = 0; k < n; ++k) {
+            double t = 0.0;
+            for (int r = 0; r < g->n; ++r) t += g->slot[(size_t)r * n + k];
+            g->sum[k] = t;
+        }
+        g->arrived = 0;
+        ++g->generation;
+        pthread_cond_broadcast(&g->cv);
+    } else {
+        while (g->generation == gen) pthread_cond_wait(&g->cv, &g->m);
+    }
+    memcpy(v, g->sum, (size_t)n * sizeof(double));
+    pthread_mutex_unlock(&g->m);
+    return PIGS_OK;
+}
 int pigs_selftest_fastmath(pigs_ctx *c, int32_t b, int32_t i, uint64_t bad[4]) { (void)c; (void)b; (void)i; memset(bad, 0, 32); return PIGS_OK; }

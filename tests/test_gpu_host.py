@@ -316,3 +316,26 @@ def test_gpu_device_sampler_lstag_beyond_nb(exe, name, tmp_path):
     for f in ("e_vpi.out", "et_vpi.out"):
         assert _close(tmp_path / f, os.path.join(src, f)), f
     assert _close(tmp_path / "gr_vpi.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
+
+
+@pytest.mark.parametrize("dev", ["F", "T"])
+def test_gpu_front_end_sharded_contexts_one_gpu(exe, dev, tmp_path):
+    """&gpu n_gpus = 2, same_device = T: two contexts (two host threads, two shards of walkers) on this one GPU, the
+    block-estimator vector all-reduced once per block (on duplicate devices the library's in-process rehearsal form
+    stands in for RCCL).  Per-walker files and final worldlines equal the one-context run of the same walkers; the
+    walker-summed files agree to summation order.  Host-driven and device-resident sampler."""
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read().replace("Nblock = 6", "Nblock = 3")
+    a, b = tmp_path / "one", tmp_path / "sharded"
+    a.mkdir(); b.mkdir()
+    _run(exe, base + f"&gpu\n n_walkers = 4, device = 0, n_gpus = 1, device_sampler = {dev}\n/\n", str(a))
+    _run(exe, base + f"&gpu\n n_walkers = 4, device = 0, n_gpus = 2, same_device = T, device_sampler = {dev}\n/\n", str(b))
+    assert same_bits(np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin"))
+    for w in range(4):
+        for f in ("e_vpi", "et_vpi", "gr_vpi", "nr_vpi"):
+            name = f"{f}.w{w:04d}.out"
+            assert open(a / name, "rb").read() == open(b / name, "rb").read(), name
+    for f in ("e_vpi.out", "et_vpi.out", "gr_vpi.out", "nr_vpi.out"):
+        x, y = np.loadtxt(a / f), np.loadtxt(b / f)
+        ok = np.isfinite(x)
+        assert x.shape == y.shape and np.array_equal(ok, np.isfinite(y))
+        assert np.all(np.abs(x - y)[ok] <= 1e-9 * np.abs(x[ok]) + 1e-300), f

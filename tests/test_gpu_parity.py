@@ -694,3 +694,27 @@ def test_analytic_trial_function_wf_table_false(gpu_lib, oracle, kw):
                 lo = np.array(oracle.local_energy(S, WF, VT, Paths[k][slot]))
                 if np.all(np.isfinite(lo)):
                     assert _close_rel([E[k], K[k], Pp[k]], lo), (slot, k)
+
+
+def test_commit_list_is_a_sequence_last_value_wins(gpu_lib):
+    """A commit list is the caller's program order of `Path(:,ip,ib) = x`: a bead that appears several times must end
+    up with the LAST value (the kernel writes entries in parallel; earlier duplicates are masked on the host).  The
+    host-driven sampler queues a worm's bead Nb twice before one flush (re-selection of xend between half-chain moves)."""
+    t = load_golden("tables_he4_n64")
+    cfg = config_from_golden(t)
+    rng = np.random.default_rng(8)
+    W = 5
+    Paths = rng.uniform(-1, 1, (W, cfg.M, cfg.Np, 3))
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        n = 4000
+        w = rng.integers(0, W, n).astype(np.int32)
+        ip = rng.integers(1, 4, n).astype(np.int32)          # few particles, few beads: many duplicates
+        ib = rng.integers(0, 6, n).astype(np.int32)
+        x = rng.normal(0, 1, (n, 3))
+        ctx.commit_beads(w, ip, ib, x)
+        got = ctx.download_all()
+    want = Paths.copy()
+    for i in range(n):
+        want[w[i], ib[i], ip[i] - 1] = x[i]
+    assert same_bits(got, want)

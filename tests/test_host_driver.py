@@ -145,3 +145,33 @@ def test_own_checkpoint_round_trip(exe, tmp_path):
     # the checkpoint is the reference's text format: trap, isopen, iworm, Np*(2Nb+1) bead lines, 2 blank, 2 xend
     lines = open(b / "checkpoint.dat").read().split("\n")
     assert lines[0].strip() == ".False." and len([l for l in lines if l.strip()]) == 3 + 16 * 17 + 2
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_walkers_sharded_over_contexts_equal_one_context(exe, G, tmp_path):
+    """&gpu n_gpus = G (BASELINE config 4's structure: walkers in contiguous shards, one context + one host thread per
+    shard, ONE all-reduce of the block-estimator vector per block -- here between CPU-shim contexts): every walker's
+    files, the final worldlines and the walker-summed files equal the single-context run of the same 5 walkers (walker
+    w runs the chain of seed+w-1 whatever the partition; sums over walkers differ by their order only)."""
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read().replace("Nblock = 6", "Nblock = 3")
+    a, b = tmp_path / "one", tmp_path / "sharded"
+    a.mkdir(); b.mkdir()
+    run_pigs_vpi(exe, base + "&gpu\n n_walkers = 5, device = 0, n_gpus = 1\n/\n", str(a))
+    run_pigs_vpi(exe, base + f"&gpu\n n_walkers = 5, device = 0, n_gpus = {G}, same_device = T\n/\n", str(b))
+    assert f"GPUs (walker shards):{G:6d}" in open(b / "stdout.txt").read()
+    assert same_bits(np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin"))
+    for w in range(5):
+        for f in FILES + ["perm_vpi.out", "e_vpi.hex"]:
+            name = f.replace(".out", f".w{w:04d}.out").replace(".hex", f".w{w:04d}.hex")
+            assert open(a / name, "rb").read() == open(b / name, "rb").read(), name
+    # walker w of the sharded run is the reference run of seed 1982 + w
+    for w, seed in enumerate((1982, 1983, 1984)):
+        src = os.path.join(RUNS, f"he4_worm_s{seed}")
+        ref = np.atleast_2d(np.loadtxt(os.path.join(src, "e_vpi.out")))
+        assert np.array_equal(np.atleast_2d(np.loadtxt(b / f"e_vpi.w{w:04d}.out")), ref[ref[:, 0] <= 3])
+    # the walker-summed files (written by shard 1 from the reduced vector)
+    for f in ("e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out"):
+        x, y = np.loadtxt(a / f), np.loadtxt(b / f)
+        assert x.shape == y.shape and x.size > 0, f
+        ok = np.isfinite(x)
+        assert np.array_equal(ok, np.isfinite(y)) and np.all(np.abs(x - y)[ok] <= 1e-9 * np.abs(x[ok]) + 1e-300), f
