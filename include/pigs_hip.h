@@ -52,6 +52,8 @@ typedef struct pigs_ctx pigs_ctx;
 /* Replaces the module-global set-up of vpi.f90:76-153 for the hot path: uploads both
  * tables (built host-side by the caller exactly as vpi_mod.f90:84-145 builds them, or
  * by pigs_build_tables) and reserves HBM for n_walkers resident worldlines. */
+/* wf_table = 0 (the reference's default, vpi_mod.f90:59): the trial function is evaluated analytically (McMillan
+ * u(r) = -0.5 (Rm/r)^5, system_mod.f90:38-66) and LogWF may be NULL.  v_table = 1 is mandatory (quirk Q3). */
 int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *LogWF,
                     int32_t n_walkers, int32_t device_id, pigs_ctx **out);
 int pigs_ctx_destroy(pigs_ctx *ctx);
@@ -65,17 +67,24 @@ int pigs_stream(pigs_ctx *ctx, void **hip_stream);
 
 /* Tuning knobs.
  *   "k1_variant": which Delta-S kernel pigs_delta_action_* runs.
- *        0  auto (default): periodic systems use the short arithmetic -- every per-pair term to ~1 ulp, cutoff
- *           membership unchanged -- in the persistent LDS-table kernel (12) for launches of
- *           >= 16 items per CU with Np <= 256, else in the plain grid (8 / 7); trapped systems use 2
+ *        0  auto (default).  The arithmetic follows from the SYSTEM, never from the size of a launch (an item's bits
+ *           must not depend on what else travels with it): periodic systems with Np <= 256 use the short arithmetic
+ *           -- every per-pair term to ~1 ulp, cutoff membership unchanged -- in the persistent
+ *           LDS-table kernel (12) for launches of >= 16 items per CU and in its plain-grid twin (13, identical bits)
+ *           below that; periodic systems beyond 256 particles use 7; trapped systems use 2
  *        1  plain statement of the reference's arithmetic          2  same terms bit for bit, short exact division
- *        3  2 + table in LDS      4  2 + in-cutoff compaction      5  3 + 4        6  2 + prefetch
- *        7  short arithmetic      8  7 + prefetch     9 / 10  7 / 8 + table in LDS
- *        11 persistent LDS-table kernel, branch-free               12  11 + records / coordinates requested ahead
- *      1-6 agree with each other up to the order of the sums; 7-12 likewise, and with 1-6 to ~1e-15 per term.
+ *        7  short arithmetic on the global table                   8  7 + partner loads issued up front
+ *        12 persistent LDS-table kernel, branch-free short arithmetic, look-ahead loads
+ *        13 the per-item arithmetic of 12 on a plain grid (global table image)
+ *        14 validation: the terms of 2 added in the reference's jp order -- Delta S, DeltaPot, DeltaF2 and DeltaLogPsi
+ *           equal the reference's bit for bit (BASELINE config 2's "pair-action kernel vs CPU bit-compare")
+ *      1, 2 and 14 sum bit-identical terms (1 / 2 in lane-strided order); 7-13 agree with them to ~1e-15 per term.
+ *      (3-6, 9-11 were A/B forms of round 1 and are gone.)
  *      The environment variable PIGS_K1_VARIANT presets this key at pigs_ctx_create (test hook).
- *   "sweep_threads": workgroup size of the device-resident sampler (256 / 512 / 1024); "sweep_debug": timing
- *      experiments of that kernel (results become meaningless). */
+ *   "sweep_threads": workgroup size of the device-resident sampler (>= 512: the one-workgroup-per-CU form, 256: three
+ *      workgroups per CU).  "sweep_split": 1 runs the diagonal bisection moves of a periodic system in the stage-machine
+ *      kernel (pigs_diag.hip, three launches per MC step) instead of the one-launch kernel; it is chosen automatically
+ *      for Nlev > 4. */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */
@@ -136,6 +145,8 @@ int pigs_delta_action_parts(pigs_ctx *ctx, int64_t n_items,
                             const int32_t *walker, const int32_t *ip, const int32_t *ib,
                             const double *xnew, const double *xold, double *parts);
 
+/* A commit list is a sequence of assignments in the caller's program order: if a bead appears more than once, the last
+ * value wins. */
 /* ---- K5: commit (replaces `Path(k,ip,ib)=xnew(k)` on accept / OldChain restore, e.g.
  * vpi_mod.f90:370-374,948,987-995) -------------------------------------------------- */
 int pigs_commit_beads(pigs_ctx *ctx, int64_t n, const int32_t *walker, const int32_t *ip,
@@ -209,9 +220,10 @@ int pigs_structure_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32
 
 /* ---- multi-GPU: block-estimator reduction (new) ------------------------ */
 /* RCCL communicator over `nranks` contexts.  Single-process form (one host thread per
- * GPU, the Fortran host): pigs_comm_init_all.  Multi-process form: rank 0 obtains an id
+ * GPU, the Fortran host: pigs_vpi's &gpu n_gpus = G): pigs_comm_init_all.  Multi-process form: rank 0 obtains an id
  * with pigs_comm_unique_id, distributes the 128 bytes out of band, every rank calls
- * pigs_comm_init_rank. */
+ * pigs_comm_init_rank.  pigs_comm_init_all on contexts that share a device (a one-GPU rehearsal) sets up an
+ * in-process reduction instead of RCCL: same semantics (ranks added in rank order), no xGMI. */
 int pigs_comm_unique_id(char id[128]);
 int pigs_comm_init_rank(pigs_ctx *ctx, int32_t nranks, int32_t rank, const char id[128]);
 int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks);

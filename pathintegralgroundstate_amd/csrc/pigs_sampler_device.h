@@ -175,9 +175,15 @@ __device__ __forceinline__ double image_next(const DevParams &P, bool trap, int 
 // Metropolis question on exp(a) (vpi_mod.f90:356-364); call from ONE lane
 __device__ __forceinline__ bool metropolis(const Rng &R, double a)
 {
-    if (a >= 0.0) return true;                  // exp(a) >= 1 without evaluating it (NaN falls through, as before)
-    const double e = exp(a);
-    if (e >= 1.0) return true;                  // -2^-54 < a < 0 still rounds to 1: no uniform is drawn (as the reference)
+    if (a >= -0x1p-54) return true;             // exp(a) rounds to >= 1: no uniform is drawn (as the reference)
+    const int pos = R.ctl[0];
+    if (a == a && R.ctl[12] > pos) {            // log(u) of the next uniform is tabulated (rng_produce): a >= log(u)
+        const double lu = R.Lc[pos % kGRing];   // is the same question without exp(); the two forms differ only when
+        R.ctl[0] = pos + 1;                     // exp(a) and u agree to the last bit
+        return a >= lu;
+    }
+    const double e = exp(a);                    // look-ahead exhausted, or NaN (draws a uniform, rejects)
+    if (e >= 1.0) return true;
     return e >= take1(R);
 }
 
