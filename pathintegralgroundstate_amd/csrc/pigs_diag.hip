@@ -46,6 +46,17 @@ __device__ __forceinline__ void lds_barrier()
 }
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// value of lane (i + N) of the same row of 16 lanes (DPP row_shl:N; 0 beyond the row): no LDS round trip
+template <int N>
+__device__ __forceinline__ double row_shl(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x100 + N, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x100 + N, 0xf, 0xf, true);
+    return r.d;
+}
+
 struct DiagLds {
     size_t mt, ctl, Gc, Lc, pc0, pc1, dS, cn, gbuf, sxn, sxo, sb, dxs, sgn, sgb, tots, red, tab, total;
 };
@@ -184,6 +195,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
         DSTAMP(tA);
         if (wid == 0) {
             // ================= control step =================
+            DSTAMP(c0);
             // the producer only works in task phases: its marks are stable here.  One refill makes sure that the two
             // uniforms and the one window of candidates a step can take are there (anything beyond goes the slow way).
             int gd = ctl[12];
@@ -193,6 +205,17 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 rng_background(R, lane);
                 gd = ctl[12];
             }
+            // everything the step may read from LDS whatever the pending decision turns out to be is requested now, in one go
+            double pre_tv[4];
+            {
+                const int tpb0 = 1 << c_lgtpb;
+                const bool on = c_kind == 0 && lane < c_nbd * 8 && tpb0 <= 4;
+                const double *Tb = tots + (on ? (lane >> 3) * tpb0 * 8 + (lane & 7) : 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pre_tv[t] = Tb[(on && t < tpb0 ? t : 0) * 8];
+            }
+            const int    pre_b  = sb[(c_kind == 0 && lane < c_nbd * 8) ? (lane >> 3) : 0];
+            const double pre_lu = Lc[pos & (kGRing - 1)];                     // log u of the pending Metropolis question
             bool ok = false;
             if (c_kind == 0) {
                 // ---- finish the pending bisection stage: column sums of each bead's tasks (lane = bead*8 + column)
@@ -203,47 +226,43 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                     if (lane < c_nbd) dSi = item_finish_split<DIM>(P, sb[lane], tpb, tots + (size_t)lane * tpb * 8);
                     tsum = 0.0;
                     for (int i = 0; i < c_nbd; ++i) tsum = tsum + read_lane(dSi, i);
-                } else {
+                } else if (tpb > 4) {                                         // Np > 256 or fewer task waves: columns through LDS
                     double cs = 0.0;
-                    {
-                        // eight loads in flight (idle lanes and absent tasks read cell 0 and add zero)
-                        const bool on = lane < c_nbd * 8;
-                        const double *Tb = tots + (on ? (lane >> 3) * tpb * 8 + (lane & 7) : 0);
-                        double tv[8];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) tv[t] = Tb[(t < tpb ? t : 0) * 8];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) cs = cs + ((on && t < tpb) ? tv[t] : 0.0);
-                        for (int t = 8; t < tpb; ++t) cs = cs + (on ? Tb[t * 8] : 0.0);   // Np > 256
+                    if (lane < c_nbd * 8) {
+                        const double *Tb = tots + (lane >> 3) * tpb * 8 + (lane & 7);
+                        for (int t = 0; t < tpb; ++t) cs = cs + Tb[t * 8];
                     }
                     red[lane] = cs;
                     __builtin_amdgcn_wave_barrier();
                     double dSi = 0.0;
-                    if (lane < c_nbd) {
-                        const double *C = red + lane * 8;
-                        const int b = sb[lane];
-                        const bool odd  = (b & 1) != 0;
-                        const bool endb = (b == 0) || (b == 2 * Nb);
-                        const double dPot = C[0] - C[1];
-                        double dF2 = 0.0, dPsi = 0.0;
-                        if (odd) {
-                            double fn2 = 0.0, fo2 = 0.0;
-#pragma unroll
-                            for (int kk = 0; kk < DIM; ++kk) { fn2 = fn2 + C[2 + kk] * C[2 + kk]; fo2 = fo2 + C[5 + kk] * C[5 + kk]; }
-                            dF2 = fn2 - fo2;
-                        } else if (endb) {
-                            dPsi = C[2] - C[3];
-                        }
-                        dSi = -dPsi + green_function_action(b, Nb, P.dt, dPot, dF2);
-                    }
+                    if (lane < c_nbd) dSi = item_finish_split<DIM>(P, sb[lane], 1, red + lane * 8);
                     __builtin_amdgcn_wave_barrier();
                     tsum = 0.0;
                     for (int i = 0; i < c_nbd; ++i) tsum = tsum + read_lane(dSi, i);
+                } else {
+                    // lane = bead*8 + column: the column sums of the bead's (<= 4) tasks, then Delta S in the bead's first
+                    // lane with its neighbours' columns fetched by DPP row shifts (no LDS round trip), in the reference's
+                    // order: DeltaPot = c0 - c1, Fnew2 = (f0^2 + f1^2) + f2^2 (vpi_mod.f90:2825-2838)
+                    const bool on = lane < c_nbd * 8;
+                    double cs = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cs = cs + ((on && t < tpb) ? pre_tv[t] : 0.0);
+                    const double d01 = cs - row_shl<1>(cs);                   // column 0: DeltaPot; column 2: PsiNew - PsiOld
+                    const double sq  = cs * cs;
+                    const double f2  = (sq + row_shl<1>(sq)) + row_shl<2>(sq);   // column 2: |Fnew|^2; column 5: |Fold|^2
+                    const double fn2 = row_shl<2>(f2), fo2 = row_shl<5>(f2), dps = row_shl<2>(d01);
+                    const int b = pre_b;
+                    const bool odd  = (b & 1) != 0;
+                    const bool endb = (b == 0) || (b == 2 * Nb);
+                    const double dSi = -(endb ? dps : 0.0) + green_function_action(b, Nb, P.dt, d01, odd ? fn2 - fo2 : 0.0);
+                    tsum = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (i < c_nbd) tsum = tsum + read_lane(dSi, 8 * i);
                 }
                 // Metropolis (vpi_mod.f90:960-969) on exp(-tsum), asked as -tsum >= log(u)
                 const double a = -tsum;
                 if (a >= -0x1p-54) ok = true;                                 // exp(a) rounds to >= 1: no uniform is drawn
-                else if (a == a) { ok = a >= Lc[pos & (kGRing - 1)]; ++pos; }
+                else if (a == a) { ok = a >= pre_lu; ++pos; }
                 else {                                                        // NaN: the plain form (draws a uniform, rejects)
                     if (lane == 0) { ctl[0] = pos; (void)metropolis(R, a); }
                     __builtin_amdgcn_wave_barrier();
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 t = wave_sum(t);
                 const double a = -t;
                 if (a >= -0x1p-54) ok = true;
-                else if (a == a) { ok = a >= Lc[pos & (kGRing - 1)]; ++pos; }
+                else if (a == a) { ok = a >= pre_lu; ++pos; }
                 else {
                     if (lane == 0) { ctl[0] = pos; (void)metropolis(R, a); }
                     __builtin_amdgcn_wave_barrier();
@@ -296,6 +315,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 if (lane == 0) { ++cnt[14]; cnt[0] += ok; }
                 cmv = 3;                                                      // visit finished
             }
+            DSTAMP(c1);
             // ---- the next stage
             int flags = 0;
             bool quit = false;
@@ -347,6 +367,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 // ---- bisection-type stage clev of move cmv on beads cii..cii+cseg:
                 //   clev == 0: the free guess of the end bead of a head / tail move with its own test (Q12)
                 //   clev >= 1: the 2^(clev-1) midpoints of the level (vpi_mod.f90:903-971)
+                DSTAMP(c2);
                 const int nbd = clev == 0 ? 1 : 1 << (clev - 1);
                 const int G = nbd * DIM;
                 // G Gaussians = the first G accepted polar pairs at pos, pos+2, ... (= G sequential rangauss calls)
@@ -367,6 +388,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                         pos = ctl[0];
                     }
                 }
+                DSTAMP(c3);
                 const double *pcur = pcb[ccur];
                 const int dib = clev == 0 ? 0 : cseg >> (clev - 1);
                 const double sigma = clev == 0 ? sgn[cseg] : sgb[cnl - clev + 1];
@@ -416,6 +438,8 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                     ctl[0] = pos;
                 }
                 ++c_phase;
+                DSTAMP(c4);
+                DACC(0, c0, c1); DACC(1, c1, c2); DACC(2, c2, c3); DACC(3, c3, c4);
             }
         }
         DSTAMP(tB);
