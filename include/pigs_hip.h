@@ -189,8 +189,9 @@ int pigs_sampler_counters16(pigs_ctx *ctx, int64_t *cnt);
 /* worm state of every walker: isopen[w], iworm[w] (1-based), xend(dim,2,w) */
 int pigs_sampler_get_worm(pigs_ctx *ctx, int32_t *isopen, int32_t *iworm, double *xend);
 int pigs_sampler_set_worm(pigs_ctx *ctx, const int32_t *isopen, const int32_t *iworm, const double *xend);
-/* events of the LAST step, 64 ints per walker: [0] n, [1] isopen after the step, then (code,arg) pairs in
- * order: 1 open accepted (arg iworm) 2 close accepted 3 swap accepted (arg partner) */
+/* events of the LAST step, pigs_sampler_event_ints() = max(64, 4 + 2*(1+Nobdm)) ints per walker: [0] n, [1] isopen after
+ * the step, then (code,arg) pairs in order: 1 open accepted (arg iworm) 2 close accepted 3 swap accepted (arg partner) */
+int pigs_sampler_event_ints(pigs_ctx *ctx, int32_t *n);
 int pigs_sampler_events(pigs_ctx *ctx, int32_t *events);
 /* OBDM histogram nrho(0:Npw,Nbin,w) accumulated on the device since walker w's last reset; reset == NULL
  * keeps everything, otherwise walker w's histogram is zeroed after the copy where reset[w] != 0 (the

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
     "pigs_sampler_counters", "pigs_sampler_counters16", "pigs_sampler_get_worm", "pigs_sampler_set_worm",
-    "pigs_sampler_events", "pigs_sampler_nrho", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
+    "pigs_sampler_events", "pigs_sampler_event_ints", "pigs_sampler_nrho", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_get_worm.argtypes = [vp, _ip, _ip, _dp]
     L.pigs_sampler_set_worm.argtypes = [vp, _ip, _ip, _dp]
     L.pigs_sampler_events.argtypes = [vp, _ip]
+    L.pigs_sampler_event_ints.argtypes = [vp, C.POINTER(C.c_int32)]
     L.pigs_sampler_nrho.argtypes = [vp, _dp, _ip]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
@@ -356,7 +357,9 @@ class PigsContext:
         _chk(self.L, self.L.pigs_sampler_set_worm(self.h, _i(isopen), _i(iworm), _d(xend)), "pigs_sampler_set_worm")
 
     def sampler_events(self):
-        ev = np.zeros((self.n_walkers, 64), np.int32)
+        n = C.c_int32()
+        _chk(self.L, self.L.pigs_sampler_event_ints(self.h, C.byref(n)), "pigs_sampler_event_ints")
+        ev = np.zeros((self.n_walkers, n.value), np.int32)
         _chk(self.L, self.L.pigs_sampler_events(self.h, _i(ev)), "pigs_sampler_events")
         return ev
 

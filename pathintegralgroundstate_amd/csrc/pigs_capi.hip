@@ -574,7 +574,6 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     const bool worm = sp->CWorm > 0.0;
     if (worm && (sp->Nobdm < 0 || sp->Nbin < 1 || sp->Npw < 0 || !(sp->rbin > 0.0) || !(sp->density > 0.0)))
         return fail(PIGS_ERR_ARG, "worm parameters out of range");
-    if (worm && 2 + 2 * (1 + sp->Nobdm) > kEvInts) return fail(PIGS_ERR_UNSUPPORTED, "Nobdm=%d exceeds the event log", sp->Nobdm);
     SweepParams &k = c->sweep;
     memset(&k, 0, sizeof k);
     k.Nlev = sta ? 1 : sp->Nlev; k.Nstag = sp->Nstag; k.Lstag = sp->Lstag; k.staging = sta;
@@ -599,7 +598,10 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     if (!c->d_rng) HIPCHK(hipMalloc((void **)&c->d_rng, W * kRngWords * sizeof(uint32_t)));
     if (!c->d_counters) HIPCHK(hipMalloc((void **)&c->d_counters, W * kCounters * sizeof(unsigned long long)));
     if (!c->d_worm) HIPCHK(hipMalloc((void **)&c->d_worm, W * kWormDoubles * sizeof(double)));
-    if (!c->d_evlog) HIPCHK(hipMalloc((void **)&c->d_evlog, W * kEvInts * sizeof(int)));
+    // a step logs at most one open / close event and one swap per OBDM iteration
+    k.ev_ints = kEvInts > 4 + 2 * (1 + k.Nobdm) ? kEvInts : 4 + 2 * (1 + k.Nobdm);
+    if (c->d_evlog) { HIPCHK(hipFree(c->d_evlog)); c->d_evlog = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->d_evlog, W * k.ev_ints * sizeof(int)));
     if (c->d_nrho) { HIPCHK(hipFree(c->d_nrho)); c->d_nrho = nullptr; }
     c->nrho_doubles = W * (size_t)k.Nbin * (k.Npw + 1);
     HIPCHK(hipMalloc((void **)&c->d_nrho, c->nrho_doubles * sizeof(double)));
@@ -614,7 +616,7 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     HIPCHK(hipMemcpyAsync(c->d_dklog, dk.data(), dk.size() * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, W * kCounters * sizeof(unsigned long long), s));
     HIPCHK(hipMemsetAsync(c->d_worm, 0, W * kWormDoubles * sizeof(double), s));
-    HIPCHK(hipMemsetAsync(c->d_evlog, 0, W * kEvInts * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(c->d_evlog, 0, W * k.ev_ints * sizeof(int), s));
     HIPCHK(hipMemsetAsync(c->d_nrho, 0, c->nrho_doubles * sizeof(double), s));
     std::vector<uint32_t> st(W * kRngWords);
     for (size_t w = 0; w < W; ++w) {
@@ -744,11 +746,19 @@ int pigs_sampler_set_worm(pigs_ctx *c, const int32_t *isopen, const int32_t *iwo
     return PIGS_OK;
 }
 
+int pigs_sampler_event_ints(pigs_ctx *c, int32_t *n)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->sampler_ready || !n) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
+    *n = c->sweep.ev_ints;
+    return PIGS_OK;
+}
+
 int pigs_sampler_events(pigs_ctx *c, int32_t *events)
 {
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready || !events) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
-    HIPCHK(hipMemcpyAsync(events, c->d_evlog, (size_t)c->n_walkers * kEvInts * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(events, c->d_evlog, (size_t)c->n_walkers * c->sweep.ev_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PIGS_OK;
 }

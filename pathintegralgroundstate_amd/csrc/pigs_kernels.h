@@ -58,12 +58,13 @@ hipError_t launch_swap_tails(const DevParams &P, double *paths, int walker, int 
 constexpr int kRngWords = 2 * 624 + 1;
 constexpr int kCounters = 16;       // per-walker move counters (pigs_sampler.hip)
 constexpr int kWormDoubles = 8;     // isopen, iworm, xend(:,1), xend(:,2)
-constexpr int kEvInts = 64;         // event log of one MC step
+constexpr int kEvInts = 64;         // event log of one MC step: at least this many ints per walker (SweepParams.ev_ints)
 struct SweepParams {
     int32_t Nlev, Nstag, Lstag, do_cm;
     int32_t open_attempt, parts, worm, swapping;  // worm: CWorm > 0 (open/close/swap sector sampled); parts: sections of the
                                                   // step a launch runs (1 open/close attempt, 2 diagonal moves, 4 worm moves)
     int32_t Nobdm, Nbin, Npw, staging;            // staging: sampling = 'sta' in the diagonal sector
+    int32_t ev_ints, pad1;                        // ints per walker of the event log: max(kEvInts, 4 + 2*(1+Nobdm))
     double  delta_cm, log_cworm_density, rbin;
 };
 hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,

@@ -320,6 +320,13 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_structure_batch
 
+     function pigs_sampler_event_ints(ctx,n) bind(C,name='pigs_sampler_event_ints') result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int32_t) :: n
+       integer(c_int) :: rc
+     end function pigs_sampler_event_ints
+
      function pigs_comm_init_all(ctxs,nranks) bind(C,name='pigs_comm_init_all') result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr)               :: ctxs(*)

@@ -316,7 +316,8 @@ contains
      swp_par%sampling = merge(1,0,sampling=="sta")
      swp_par%swapping = merge(1,0,swapping); swp_par%Nobdm = Nobdm; swp_par%Nbin = Nbin; swp_par%Npw = Npw
      call pigs_check(pigs_sampler_init(ctx,swp_par),'pigs_sampler_init')
-     allocate (dev_open(NW),dev_iworm(NW),dev_ev(64,NW),dev_nrho(0:Npw,Nbin,NW),dev_reset(NW))
+     call pigs_check(pigs_sampler_event_ints(ctx,rpos),'pigs_sampler_event_ints')
+     allocate (dev_open(NW),dev_iworm(NW),dev_ev(rpos,NW),dev_nrho(0:Npw,Nbin,NW),dev_reset(NW))
      dev_open = merge(1,0,s%isopen); dev_iworm = s%iworm
      call pigs_check(pigs_sampler_set_worm(ctx,dev_open,dev_iworm,s%xend),'pigs_sampler_set_worm')
      do w=1,NW

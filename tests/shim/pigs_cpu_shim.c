@@ -208,6 +208,7 @@ int pigs_sampler_counters16(pigs_ctx *c, int64_t *a) { (void)c; (void)a; return 
 int pigs_sampler_get_worm(pigs_ctx *c, int32_t *o, int32_t *i, double *x) { (void)c; (void)o; (void)i; (void)x; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_set_worm(pigs_ctx *c, const int32_t *o, const int32_t *i, const double *x) { (void)c; (void)o; (void)i; (void)x; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_events(pigs_ctx *c, int32_t *e) { (void)c; (void)e; return PIGS_ERR_UNSUPPORTED; }
+int pigs_sampler_event_ints(pigs_ctx *c, int32_t *n) { (void)c; (void)n; return PIGS_ERR_UNSUPPORTED; }
 int pigs_sampler_nrho(pigs_ctx *c, double *n, const int32_t *r) { (void)c; (void)n; (void)r; return PIGS_ERR_UNSUPPORTED; }
 int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)
 {

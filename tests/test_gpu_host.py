@@ -236,7 +236,9 @@ def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     ("sta", "dim = 3, Np = 21, density = 0.2d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0"),
     # beyond the one-launch kernel's four levels: 2^5, 2^6 beads per bisection segment (pigs_diag.hip's stage machine)
     ("bis", "dim = 3, Np = 20, density = 0.3d0", "Nb = 40, Lstag = 30, Nlev = 6", "0.0d0"),
-    ("bis", "dim = 3, Np = 70, density = 0.3d0", "Nb = 20, Lstag = 8, Nlev = 5", "0.4d0")])
+    ("bis", "dim = 3, Np = 70, density = 0.3d0", "Nb = 20, Lstag = 8, Nlev = 5", "0.4d0"),
+    # more OBDM iterations per step than round 1's fixed 64-int event log could hold (Nobdm <= 30)
+    ("bis", "dim = 3, Np = 12, density = 0.3d0", "Nb = 10, Lstag = 6, Nlev = 2", "2.0d0, Nobdm = 45")])
 def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, sampling, extra, samp, cworm):
     """No reference run exists for these shapes; the host-driven sampler (bit-identical to the reference wherever
     a fixture exists) is the yardstick: same input, three walkers, device_sampler = F and T must give the same
@@ -250,7 +252,7 @@ def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, 
  Nblock = 3, Nstep = 12, Nbin = 50, Nk = 10
 /
 &obdm
- swapping = T, CWorm = {cworm}, Nobdm = 3, Npw = 1
+ swapping = T, Nobdm = 3, Npw = 1, CWorm = {cworm}
 /
 &wavefun
  Nmax = 4000, wf_table = T, v_table = T
