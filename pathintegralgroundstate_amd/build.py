@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpigs_hip.so")
-SOURCES = ["pigs_k1.hip", "pigs_sampler.hip", "pigs_diag.hip", "pigs_kernels.hip", "pigs_capi.hip", "pigs_comm.cpp", "pigs_tables.cpp"]
+SOURCES = ["pigs_k1.hip", "pigs_sampler.hip", "pigs_diag.hip", "pigs_cm.hip", "pigs_kernels.hip", "pigs_capi.hip", "pigs_comm.cpp", "pigs_tables.cpp"]
 HEADERS = ["pigs_device.h", "pigs_k1_device.h", "pigs_kernels.h", "pigs_comm.h", "pigs_sampler_device.h"]
 # -ffp-contract=off: every per-pair term must round exactly like the reference's x86-64
 # build (no FMA); hipcc's default is fast contraction.

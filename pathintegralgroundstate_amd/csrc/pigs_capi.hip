@@ -123,6 +123,11 @@ struct pigs_ctx {
     int         sweep_threads = 512;
     bool        sweep_split = false;    // diagonal moves of periodic 'bis' systems in pigs_diag.hip's kernel (see pigs_sampler_step)
     int         n_cu = 256;
+    // TranslateChain by several workgroups per walker (pigs_cm.hip): -1 as many as fit (default), 0 off, H >= 1 at most H
+    int         cm_split = -1;
+    unsigned long long *d_xch = nullptr;    // exchange buffer of the cooperating workgroups
+    int        *h_cm_err = nullptr;         // (pinned, device-visible) set by a workgroup whose partner never answered
+    unsigned int cm_seq = 1;                // sequence tags of the exchange: advanced by every launch
     bool        sampler_ready = false;
 };
 
@@ -258,6 +263,8 @@ int pigs_ctx_destroy(pigs_ctx *c)
     if (c->d_nrho) (void)hipFree(c->d_nrho);
     if (c->d_dklog) (void)hipFree(c->d_dklog);
     if (c->d_evlog) (void)hipFree(c->d_evlog);
+    if (c->d_xch) (void)hipFree(c->d_xch);
+    if (c->h_cm_err) (void)hipHostFree(c->h_cm_err);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_VT) (void)hipFree(c->d_VT);
@@ -268,11 +275,19 @@ int pigs_ctx_destroy(pigs_ctx *c)
     return PIGS_OK;
 }
 
+// after a synchronisation: did a cooperating workgroup of the TranslateChain kernel give up waiting (pigs_cm.hip)?
+static int check_cm(pigs_ctx *c)
+{
+    if (c->h_cm_err && *(volatile int *)c->h_cm_err)
+        return fail(PIGS_ERR_HIP, "TranslateChain kernel: a cooperating workgroup timed out; the worldlines of this context are invalid");
+    return PIGS_OK;
+}
+
 int pigs_sync(pigs_ctx *c)
 {
     int rc = check_ctx(c); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    return PIGS_OK;
+    return check_cm(c);
 }
 
 int pigs_stream(pigs_ctx *c, void **s)
@@ -292,6 +307,11 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
     }
     if (!strcmp(key, "sweep_split")) {          // 1: stage-machine kernel (pigs_diag.hip) for the diagonal bisection moves; 0 (default): one kernel
         c->sweep_split = value != 0;
+        return PIGS_OK;
+    }
+    if (!strcmp(key, "cm_split")) {             // TranslateChain by H workgroups per walker (pigs_cm.hip): -1 auto, 0 off, H = 1..4
+        if (value < -1 || value > 4) return fail(PIGS_ERR_ARG, "cm_split=%d", value);
+        c->cm_split = value;
         return PIGS_OK;
     }
     if (!strcmp(key, "sweep_threads")) {
@@ -673,13 +693,49 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     // and the worm moves (any Nlev with 2^Nlev <= 2 Nb, Nlev <= 7).  Measured at N=256, 161 beads, 128 walkers: 48.1 ms
     // vs 56.5 ms per MC step (profiles/r02_k6_stage_machine.txt), so the stage machine runs only where the other form
     // cannot, or on request (pigs_set_tuning "sweep_split" = 1).
+    //
+    // TranslateChain -- the one arithmetic-bound stage -- goes to H cooperating workgroups per walker (pigs_cm.hip) while
+    // the chip has H >= 2 CUs per walker (bit-identical trajectory whatever H): open / close attempt, that kernel, the rest.
+    int H = 0;
+    if (c->cm_split != 0 && sp.do_cm) {
+        H = cm_helpers(c->P, sp, c->n_cu);                    // what the chip holds (0: the kernel does not apply)
+        if (c->cm_split > 0) H = H < c->cm_split ? H : c->cm_split;      // on request: also H = 1
+        else if (H < 2) H = 0;
+    }
+    bool cm_done = false;
+    if (H >= 1) {
+        if (!c->d_xch) {
+            const size_t nb = cm_exchange_words(c->P) * sizeof(unsigned long long);
+            HIPCHK(hipMalloc((void **)&c->d_xch, nb));
+            HIPCHK(hipMemsetAsync(c->d_xch, 0, nb, c->stream));
+            HIPCHK(hipHostMalloc((void **)&c->h_cm_err, sizeof(int), hipHostMallocMapped));
+            *c->h_cm_err = 0;
+        }
+        sp.parts = 1;
+        HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                            c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+        int *d_err = nullptr;
+        HIPCHK(hipHostGetDevicePointer((void **)&d_err, c->h_cm_err, 0));
+        const hipError_t e = launch_cm(c->P, sp, H, c->cm_seq, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                                       c->d_worm, c->d_xch, d_err, c->stream);
+        if (e == hipErrorCooperativeLaunchTooLarge) {        // the chip is shared: the one-workgroup form takes the moves
+            (void)hipGetLastError();
+        } else {
+            HIPCHK(e);
+            c->cm_seq += (unsigned int)c->P.Np + 1;
+            sp.do_cm = 0;
+        }
+        cm_done = true;                                       // (the open / close attempt ran)
+    }
     const bool need_split = !c->P.trap && !sp.staging && sp.Nlev > 4;
     const bool split = (c->sweep_split || need_split) && diag_supported(c->P, sp);
     if (need_split && !split) return fail(PIGS_ERR_UNSUPPORTED, "Nlev=%d needs the stage-machine kernel, which does not fit this worldline", sp.Nlev);
     if (split) {
-        sp.parts = 1;
-        HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
-                            c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+        if (!cm_done) {
+            sp.parts = 1;
+            HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                                c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
+        }
         HIPCHK(launch_diag(c->P, sp, 512, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters, c->d_worm, c->stream));
         if (sp.worm) {
             sp.parts = 4;
@@ -687,7 +743,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
                                 c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
         }
     } else {
-        sp.parts = 7;
+        sp.parts = cm_done ? 6 : 7;
         HIPCHK(launch_sweep(c->P, sp, c->sweep_threads, c->d_paths, c->d_VT, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
                             c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
     }

@@ -37,6 +37,27 @@ namespace pigs {
 
 namespace {
 
+// cold paths of the control step, kept out of line so that the stage loop stays compact (instruction cache)
+__device__ __attribute__((noinline)) void cold_refill(const Rng &R, int pos, int lane)
+{
+    if (lane == 0) R.ctl[0] = pos;
+    __builtin_amdgcn_wave_barrier();
+    rng_background(R, lane);
+}
+__device__ __attribute__((noinline)) int cold_gaussians(const Rng &R, int pos, int G, double *gbuf, int lane)
+{
+    if (lane == 0) R.ctl[0] = pos;
+    __builtin_amdgcn_wave_barrier();
+    wave_gaussians(R, G, gbuf, lane);
+    return R.ctl[0];
+}
+__device__ __attribute__((noinline)) int cold_metropolis_nan(const Rng &R, int pos, double a, int lane)
+{
+    if (lane == 0) { R.ctl[0] = pos; (void)metropolis(R, a); }
+    __builtin_amdgcn_wave_barrier();
+    return R.ctl[0];
+}
+
 // workgroup barrier that drains only this wave's LDS / scalar traffic: global loads issued before it (slice touches,
 // the next visit's chain) stay in flight across it.  Global STORES that other waves read later (an accepted move's
 // beads) are drained by the storing wave itself (stores_done) before it arrives here.
@@ -200,9 +221,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
             // uniforms and the one window of candidates a step can take are there (anything beyond goes the slow way).
             int gd = ctl[12];
             if (gd < pos + 2 * kWave + 4) {
-                if (lane == 0) ctl[0] = pos;
-                __builtin_amdgcn_wave_barrier();
-                rng_background(R, lane);
+                cold_refill(R, pos, lane);
                 gd = ctl[12];
             }
             // everything the step may read from LDS whatever the pending decision turns out to be is requested now, in one go
@@ -263,11 +282,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 const double a = -tsum;
                 if (a >= -0x1p-54) ok = true;                                 // exp(a) rounds to >= 1: no uniform is drawn
                 else if (a == a) { ok = a >= pre_lu; ++pos; }
-                else {                                                        // NaN: the plain form (draws a uniform, rejects)
-                    if (lane == 0) { ctl[0] = pos; (void)metropolis(R, a); }
-                    __builtin_amdgcn_wave_barrier();
-                    pos = ctl[0];
-                }
+                else pos = cold_metropolis_nan(R, pos, a, lane);              // NaN: the plain form (draws a uniform, rejects)
                 if (ok && clev == cnl) {
                     // accepted: the generated beads go to the chain in LDS and to the resident worldline
                     const int j0 = cmv == 0 ? 0 : 1, j1 = cmv == 1 ? cseg : cseg - 1;
@@ -293,11 +308,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 const double a = -t;
                 if (a >= -0x1p-54) ok = true;
                 else if (a == a) { ok = a >= pre_lu; ++pos; }
-                else {
-                    if (lane == 0) { ctl[0] = pos; (void)metropolis(R, a); }
-                    __builtin_amdgcn_wave_barrier();
-                    pos = ctl[0];
-                }
+                else pos = cold_metropolis_nan(R, pos, a, lane);
                 if (ok) {
                     const double *pcur = pcb[ccur];
                     for (int e = lane; e < MD; e += kWave) {
@@ -382,10 +393,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                         pos += 2 * (__builtin_ctzll(sel) + 1);
                         __builtin_amdgcn_wave_barrier();
                     } else {                                                  // (rare) more than one window
-                        if (lane == 0) ctl[0] = pos;
-                        __builtin_amdgcn_wave_barrier();
-                        wave_gaussians(R, G, gbuf, lane);
-                        pos = ctl[0];
+                        pos = cold_gaussians(R, pos, G, gbuf, lane);
                     }
                 }
                 DSTAMP(c3);
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 if (m0 + np > npass) np = npass - m0;                         // (passes were rounded up to a power of two)
                 DSTAMP(k0);
 #ifndef PIGS_DIAG_SKIP_TASKS
-                pipe_task<DIM>(P, VTp, WF, Pw + (size_t)b * sl, p, b, m0, np, sides, a, c, lane, red, tots + (size_t)t * 8);
+                pipe_task_rolled<DIM>(P, VTp, WF, Pw + (size_t)b * sl, p, b, m0, np, sides, a, c, lane, red, tots + (size_t)t * 8);
 #else
                 if (lane < 8) tots[(size_t)t * 8 + lane] = a[0] * 1e-3 + c[0] * (double)(np + sides + m0);   // timing experiment: no Delta S
 #endif
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 for (int e = tid; e < MD; e += NT) pcb[cur ^ 1][e] = Pw[(size_t)(e / DIM) * sl + (size_t)(e % DIM) * P.NpPad + pn];
             }
         }
-        if (wid == NW - 1) rng_background(R, lane);                           // nobody consumes random numbers in this phase
+        if (wid == NW - 1) cold_refill(R, ctl[0], lane);                      // nobody consumes random numbers in this phase
         if (kind == 0 && (flags & 4)) {
             // first phase of a move: one load instruction per slice of the segment warms all its lines in L2 (a lane per
             // 128-byte line) for the deeper levels.  Issued behind the wave's own work and never waited for in this phase.

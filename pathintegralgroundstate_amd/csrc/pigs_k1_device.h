@@ -559,6 +559,78 @@ __device__ __forceinline__ void pipe_task_cls(const DevParams &P, PipeTab VT, co
     }
 }
 
+// The same task with the passes as a rolled loop (one pass per trip: ~1/8 of the code of pipe_task_cls).  The stage
+// machine's tasks are 1-4 passes long, and its stage loop must fit the 64 KB instruction cache that two CUs share.
+template <int DIM, int CLS>
+__device__ __forceinline__ void pipe_task_rolled_cls(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                                               const double *__restrict__ S, int p, int m0, int np, int sides,
+                                                               const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                                               double *red, double *tot8)
+{
+    Acc<DIM, CLS> A;
+    double rn[DIM];
+    {
+        const int jj = pipe_row(P, m0 * kWave + lane, p);
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) rn[k] = S[(size_t)k * P.NpPad + jj];
+    }
+#pragma nounroll
+    for (int m = m0; m < m0 + np; ++m) {
+        double rj[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) rj[k] = rn[k];
+        if (m + 1 < m0 + np) {                                        // the next pass's partners are on their way
+            const int jj = pipe_row(P, (m + 1) * kWave + lane, p);
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) rn[k] = S[(size_t)k * P.NpPad + jj];
+        }
+        const int j = m * kWave + lane;
+        const bool valid = j < P.Np && j != p;                        // row p itself never enters (vpi_mod.f90:2699)
+        if (sides & 1) {
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = xn[k] - rj[k];
+            const double r2 = min_image_rn<DIM>(d, P);
+            pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+        }
+        if (sides & 2) {
+            double d[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) d[k] = xo[k] - rj[k];
+            const double r2 = min_image_rn<DIM>(d, P);
+            pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+        }
+    }
+    if (CLS == CLS_ODD) {
+        double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
+        const double t = wave_reduce_lds<8>(v, red, lane);
+        if (lane < 8) tot8[lane] = t;
+    } else if (CLS == CLS_END) {
+        const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
+        const double t = wave_reduce_lds<4>(v, red, lane);
+        if (lane < 4) tot8[lane] = t;
+    } else {
+        const double v[2] = {A.potN, A.potO};
+        const double t = wave_reduce_lds<2>(v, red, lane);
+        if (lane < 2) tot8[lane] = t;
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ void pipe_task_rolled(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
+                                                 const double *__restrict__ S, int p, int b, int m0, int np, int sides,
+                                                 const double (&xn)[DIM], const double (&xo)[DIM], int lane,
+                                                 double *red, double *tot8)
+{
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    if (odd)       pipe_task_rolled_cls<DIM, CLS_ODD>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+    else if (endb) pipe_task_rolled_cls<DIM, CLS_END>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+    else           pipe_task_rolled_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+}
+
 template <int DIM>
 __device__ __forceinline__ void pipe_task(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
                                           const double *__restrict__ S, int p, int b, int m0, int np, int sides,

@@ -77,6 +77,12 @@ bool diag_supported(const DevParams &P, const SweepParams &sp);
 int diag_form(const DevParams &P, const SweepParams &sp, int threads);      // workgroup size launch_diag uses (0: does not fit)
 hipError_t launch_diag(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VTimg,
                        const double *WF, uint32_t *rng, unsigned long long *counters, const double *worm, hipStream_t st);
+// pigs_cm.hip: the TranslateChain moves of a periodic system by H cooperating workgroups per walker
+int cm_helpers(const DevParams &P, const SweepParams &sp, int n_cu);        // H the chip and the kernel allow (0: none)
+size_t cm_exchange_words(const DevParams &P);                               // 64-bit words of the exchange buffer
+hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned int seq0, double *paths, const double *VTimg,
+                     const double *WF, uint32_t *rng, unsigned long long *counters, const double *worm,
+                     unsigned long long *xch, int *err, hipStream_t st);
 int sweep_form(const DevParams &P, const SweepParams &sp, int threads);   // workgroup size launch_sweep uses for a request
 
 hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,

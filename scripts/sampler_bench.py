@@ -30,6 +30,8 @@ def main():
             ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe)
         if os.environ.get('SWEEP_SPLIT'):
             ctx.set_tuning('sweep_split', int(os.environ['SWEEP_SPLIT']))
+        if os.environ.get('CM_SPLIT'):
+            ctx.set_tuning('cm_split', int(os.environ['CM_SPLIT']))
         if os.environ.get('SWEEP_THREADS'):
             ctx.set_tuning('sweep_threads', int(os.environ['SWEEP_THREADS']))
         for w in range(W):

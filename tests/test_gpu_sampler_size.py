@@ -31,7 +31,7 @@ def _cfg(name):
     return SystemConfig.from_namelists(open(os.path.join(RUNS, name, "vpi.in")).read())
 
 
-def run_k6(gpu_lib, oracle, names, threads=None, split=0):
+def run_k6(gpu_lib, oracle, names, threads=None, split=0, cm=None):
     """The reference's block loop (vpi.f90:244-545) around pigs_sampler_step for the runs `names` (same input, one
     walker per seed).  Returns per walker: per-step rows [diag, E, Kin, Pot, Et, Kt], final worldline, counters16,
     generator state, worm state, events, OBDM histogram."""
@@ -49,6 +49,8 @@ def run_k6(gpu_lib, oracle, names, threads=None, split=0):
     if threads:
         ctx.set_tuning("sweep_threads", threads)
     ctx.set_tuning("sweep_split", split)          # 1: the diagonal bisection moves in pigs_diag.hip's stage machine
+    if cm is not None:
+        ctx.set_tuning("cm_split", cm)            # TranslateChain by `cm` workgroups per walker (pigs_cm.hip); 0: inside the sweep kernel
     Paths, xends = [], []
     for w, n in enumerate(names):
         P, g = oracle.init_path(S, _cfg(n).seed)
@@ -126,14 +128,30 @@ def check_against_driver(r, w):
     return worst, rel.max() if d.any() else 0.0
 
 
-@pytest.mark.parametrize("threads,split", [(None, 0), (256, 0), (None, 1)])
-def test_k6_config3_n256_161_beads(gpu_lib, oracle, threads, split):
+@pytest.mark.parametrize("threads,split,cm", [(None, 0, None), (256, 0, 0), (None, 1, None), (None, 0, 0), (None, 1, 0)])
+def test_k6_config3_n256_161_beads(gpu_lib, oracle, threads, split, cm):
     """Two walkers = the reference chains of seeds 1982 and 1983; default form (8 waves, table image in LDS), the
-    4-wave form used beyond one walker per CU, and the stage-machine kernel (pigs_diag.hip)."""
-    r = run_k6(gpu_lib, oracle, ["c3_n256_s1982", "c3_n256_s1983"], threads, split)
+    4-wave form used beyond one walker per CU, and the stage-machine kernel (pigs_diag.hip); TranslateChain by
+    cooperating workgroups (default while the chip has CUs to spare: four per walker here) and inside the sweep kernels."""
+    r = run_k6(gpu_lib, oracle, ["c3_n256_s1982", "c3_n256_s1983"], threads, split, cm)
     for w in range(2):
         worst, rel = check_against_driver(r, w)
         print(f"walker {w}: worldline max |d| = {worst:.2e}, step energies max rel = {rel:.2e}")
+
+
+def test_translate_chain_workgroups_do_not_change_the_trajectory(gpu_lib, oracle):
+    """pigs_cm.hip cuts a walker's beads into H ranges, one workgroup each; the M values of Delta S are exchanged and
+    added in bead order by every workgroup, as the one-workgroup kernel adds them: whatever H, the same bits."""
+    names = ["c3_n256_s1982", "c3_n256_s1983"]
+    ref = run_k6(gpu_lib, oracle, names, cm=0)
+    assert ref["counters"][:, 14].min() > 0                 # TranslateChain was attempted
+    for H in (1, 2, 3, 4):
+        r = run_k6(gpu_lib, oracle, names, cm=H)
+        assert np.array_equal(r["final"], ref["final"]), H
+        assert np.array_equal(r["counters"], ref["counters"]), H
+        for w in range(2):
+            assert int(r["rng"][w][0]) == int(ref["rng"][w][0]) and np.array_equal(r["rng"][w][1], ref["rng"][w][1]), H
+            assert np.array_equal(r["steps"][w], ref["steps"][w]), H
 
 
 @pytest.mark.parametrize("name", ["c5_n256_aziz_s1982", "c5_n256_dipolar_s1982"])
