@@ -368,7 +368,8 @@ def main():
         mc = {"walker_sweeps_per_s": world * W * nmc / mc_full, "ms_per_mc_step": 1e3 * mc_full / nmc,
               "moves_only": {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc},
               "walkers_per_gpu": W,
-              "kernels": "pigs::k_sweep (one launch per MC step: all moves) + k_local_energy x2, k_slice_energy, "
+              "kernels": "pigs::k_sweep (open/close attempt; bisection + worm moves) around pigs::k_cm (TranslateChain on 2 CUs per "
+                         "walker while CUs >= 2 x walkers) + k_local_energy x2, k_slice_energy, "
                          "k_therm_combine, k_structure per step",
               "accepted_moves_per_sweep_per_walker": {"cm": acc[0], "head": acc[1], "tail": acc[2], "bisection": acc[3]},
               "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in), estimators every step",

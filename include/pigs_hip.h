@@ -84,7 +84,12 @@ int pigs_stream(pigs_ctx *ctx, void **hip_stream);
  *   "sweep_threads": workgroup size of the device-resident sampler (>= 512: the one-workgroup-per-CU form, 256: three
  *      workgroups per CU).  "sweep_split": 1 runs the diagonal bisection moves of a periodic system in the stage-machine
  *      kernel (pigs_diag.hip, three launches per MC step) instead of the one-launch kernel; it is chosen automatically
- *      for Nlev > 4. */
+ *      for Nlev > 4.
+ *   "cm_split": the TranslateChain moves of a periodic system (Np <= 256) by H cooperating workgroups per walker
+ *      (pigs_cm.hip: bead ranges on H CUs, Delta S exchanged and added in bead order -- the trajectory does not depend
+ *      on H, bit for bit).  -1 (default): H = min(4, CUs / walkers) when that is >= 2; 0: inside the sweep kernel;
+ *      1..4: at most that many.  A cooperating workgroup that waits in vain (several processes crowding one chip)
+ *      gives up after seconds and the next pigs_sync returns PIGS_ERR_HIP. */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */

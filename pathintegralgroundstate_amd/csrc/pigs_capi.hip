@@ -988,7 +988,9 @@ int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks)
         auto g = std::make_shared<HostGroup>();
         g->n = nranks;
         g->slot.resize(nranks);
-        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; }
+        // (several contexts share one chip here: TranslateChain stays inside each walker's own workgroup -- the helpers
+        // of pigs_cm.hip assume the walkers of ONE context have the chip to themselves)
+        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; ctxs[i]->cm_split = 0; }
         return PIGS_OK;
     }
     const char *err = pigs_comm_create_all(comms.data(), nranks, devs.data());

@@ -25,6 +25,8 @@
 #include "pigs_kernels.h"
 #include "pigs_sampler_device.h"
 
+#include <cstdlib>
+
 namespace pigs {
 
 namespace {
@@ -214,7 +216,7 @@ int cm_helpers(const DevParams &P, const SweepParams &sp, int n_cu)
     int H = n_cu / P.nW;
     if (H > 4) H = 4;
     if (H < 1) H = 1;
-    auto fits = [&](int h) { return cm_layout(P, 8, h).total <= 160 * 1024 && (cm_range(P.M, h, 1) + 1) * P.dim <= 512; };
+    auto fits = [&](int h) { return cm_layout(P, 8, h).total <= 160 * 1024 && (cm_range(P.M, h, 1) + 1) * P.dim <= 512; };   // (the 8-wave form)
     if (!fits(H)) return 0;                      // (more workgroups = shorter ranges: if H does not fit, fewer do not either)
     return H;
 }
@@ -226,21 +228,25 @@ hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned 
                      unsigned long long *xch, int *err, hipStream_t st)
 {
     if (H < 1 || H > 4 || P.trap || (P.Nmax & 1) || P.Np > 256) return hipErrorInvalidValue;
-    const size_t lds = cm_layout(P, 8, H).total;
+    // sixteen waves (four per SIMD, 128 registers each) where their scratch fits next to the table image, eight otherwise
+    static const int want = getenv("PIGS_CM_THREADS") ? atoi(getenv("PIGS_CM_THREADS")) : 1024;
+    const int nt = (want >= 1024 && cm_layout(P, 16, H).total <= 160 * 1024) ? 1024 : 512;
+    const size_t lds = cm_layout(P, nt / kWave, H).total;
     if (lds > 160 * 1024 || (cm_range(P.M, H, 1) + 1) * P.dim > 512) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     DevParams Pk = P;
     SweepParams spk = sp;
     void *args[] = {&Pk, &spk, &H, &seq0, &paths, &VTimg, &WF, &rng, &counters, &worm, &xch, &err};
-#define CALLC(D)                                                                                                   \
+#define CALLC(D, NT)                                                                                               \
     do {                                                                                                           \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm<D, 512>),                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm<D, NT>),                                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
         if (e == hipSuccess)                                                                                       \
-            e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_cm<D, 512>), dim3(P.nW * H), dim3(512), \
+            e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_cm<D, NT>), dim3(P.nW * H), dim3(NT),  \
                                            args, (unsigned int)lds, st);                                           \
     } while (0)
-    if (P.dim == 1) CALLC(1); else if (P.dim == 2) CALLC(2); else CALLC(3);
+    if (nt == 1024) { if (P.dim == 1) CALLC(1, 1024); else if (P.dim == 2) CALLC(2, 1024); else CALLC(3, 1024); }
+    else            { if (P.dim == 1) CALLC(1, 512); else if (P.dim == 2) CALLC(2, 512); else CALLC(3, 512); }
 #undef CALLC
     return e;
 }

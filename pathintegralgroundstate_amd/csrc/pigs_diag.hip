@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 }
                 ++c_phase;
                 DSTAMP(c4);
-                DACC(0, c0, c1); DACC(1, c1, c2); DACC(2, c2, c3); DACC(3, c3, c4);
+                DACC(0, c0, c4);
             }
         }
         DSTAMP(tB);
@@ -479,7 +479,11 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                 if (m0 + np > npass) np = npass - m0;                         // (passes were rounded up to a power of two)
                 DSTAMP(k0);
 #ifndef PIGS_DIAG_SKIP_TASKS
+                #ifdef PIGS_SWEEP_TIMING
+                pipe_task_rolled<DIM>(P, VTp, WF, Pw + (size_t)b * sl, p, b, m0, np, sides, a, c, lane, red, tots + (size_t)t * 8, tacc + 1);
+#else
                 pipe_task_rolled<DIM>(P, VTp, WF, Pw + (size_t)b * sl, p, b, m0, np, sides, a, c, lane, red, tots + (size_t)t * 8);
+#endif
 #else
                 if (lane < 8) tots[(size_t)t * 8 + lane] = a[0] * 1e-3 + c[0] * (double)(np + sides + m0);   // timing experiment: no Delta S
 #endif

@@ -565,15 +565,18 @@ template <int DIM, int CLS>
 __device__ __forceinline__ void pipe_task_rolled_cls(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
                                                                const double *__restrict__ S, int p, int m0, int np, int sides,
                                                                const double (&xn)[DIM], const double (&xo)[DIM], int lane,
-                                                               double *red, double *tot8)
+                                                               double *red, double *tot8, unsigned long long *tsub = nullptr)
 {
     Acc<DIM, CLS> A;
     double rn[DIM];
+    unsigned long long q0 = 0, q1 = 0, q2 = 0;
+    if (tsub) q0 = __builtin_amdgcn_s_memtime();
     {
         const int jj = pipe_row(P, m0 * kWave + lane, p);
 #pragma unroll
         for (int k = 0; k < DIM; ++k) rn[k] = S[(size_t)k * P.NpPad + jj];
     }
+    if (tsub) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
 #pragma nounroll
     for (int m = m0; m < m0 + np; ++m) {
         double rj[DIM];
@@ -601,6 +604,7 @@ __device__ __forceinline__ void pipe_task_rolled_cls(const DevParams &P, PipeTab
             pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
         }
     }
+    if (tsub) { asm volatile("" :: "v"(A.potN), "v"(A.potO)); q2 = __builtin_amdgcn_s_memtime(); }
     if (CLS == CLS_ODD) {
         double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -616,19 +620,20 @@ __device__ __forceinline__ void pipe_task_rolled_cls(const DevParams &P, PipeTab
         const double t = wave_reduce_lds<2>(v, red, lane);
         if (lane < 2) tot8[lane] = t;
     }
+    if (tsub && threadIdx.x == 0) { const unsigned long long q3 = __builtin_amdgcn_s_memtime(); tsub[0] += q1 - q0; tsub[1] += q2 - q1; tsub[2] += q3 - q2; }
 }
 
 template <int DIM>
 __device__ __forceinline__ void pipe_task_rolled(const DevParams &P, PipeTab VT, const double *__restrict__ WF,
                                                  const double *__restrict__ S, int p, int b, int m0, int np, int sides,
                                                  const double (&xn)[DIM], const double (&xo)[DIM], int lane,
-                                                 double *red, double *tot8)
+                                                 double *red, double *tot8, unsigned long long *tsub = nullptr)
 {
     const bool odd  = (b & 1) != 0;
     const bool endb = (b == 0) || (b == 2 * P.Nb);
-    if (odd)       pipe_task_rolled_cls<DIM, CLS_ODD>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
-    else if (endb) pipe_task_rolled_cls<DIM, CLS_END>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
-    else           pipe_task_rolled_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8);
+    if (odd)       pipe_task_rolled_cls<DIM, CLS_ODD>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8, tsub);
+    else if (endb) pipe_task_rolled_cls<DIM, CLS_END>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8, tsub);
+    else           pipe_task_rolled_cls<DIM, CLS_EVEN>(P, VT, WF, S, p, m0, np, sides, xn, xo, lane, red, tot8, tsub);
 }
 
 template <int DIM>

@@ -46,7 +46,7 @@ def main():
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
         if os.environ.get('TIMING'):     # library built with PIGS_EXTRA_FLAGS=-DPIGS_SWEEP_TIMING
             c16 = ctx.sampler_counters16()[:, 8:].mean(0) / (nsteps + 1)
-            names = ['ctl: finish+metropolis', 'ctl: commit+next move', 'ctl: gaussians', 'ctl: proposal+publish', 'task: descriptor', 'task: pipe_task', 'control step total', 'bis: wait for slowest']
+            names = ['ctl: all', 'task: load wait', 'task: pair evaluations', 'task: reduce+store', 'task: descriptor', 'task: pipe_task', 'control step total', 'bis: wait for slowest']
             print('   shader-clock cycles per MC step per walker (thread 0): ' + ', '.join(f'{n} {v / 1e3:.0f}k' for n, v in zip(names, c16)), flush=True)
         if cworm > 0:
             c16 = ctx.sampler_counters16().sum(0)
