@@ -46,7 +46,10 @@ def main():
         acc = ctx.sampler_counters().sum(0) / (W * (nsteps + 1))
         if os.environ.get('TIMING'):     # library built with PIGS_EXTRA_FLAGS=-DPIGS_SWEEP_TIMING
             c16 = ctx.sampler_counters16()[:, 8:].mean(0) / (nsteps + 1)
-            names = ['ctl: all', 'task: load wait', 'task: pair evaluations', 'task: reduce+store', 'task: descriptor', 'task: pipe_task', 'control step total', 'bis: wait for slowest']
+            if os.environ.get('SWEEP_SPLIT') == '1':     # stage machine (pigs_diag.hip)
+                names = ['ctl: all', 'task: load wait', 'task: pair evaluations', 'task: reduce+store', 'task: descriptor', 'task: pipe_task', 'control step total', 'bis: wait for slowest']
+            else:                                        # one-launch kernel (pigs_sampler.hip), bisection moves
+                names = ['move: segment + chain + end guess (wave 0)', 'move: barrier', 'end bead: Delta S', 'end bead: Metropolis', 'level: Gaussians + midpoints (wave 0)', 'level: barrier', 'level: Delta S', 'level: Metropolis']
             print('   shader-clock cycles per MC step per walker (thread 0): ' + ', '.join(f'{n} {v / 1e3:.0f}k' for n, v in zip(names, c16)), flush=True)
         if cworm > 0:
             c16 = ctx.sampler_counters16().sum(0)
