@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <unordered_set>
+#include <atomic>
 #include <vector>
 
 #include "pigs_comm.h"
@@ -128,8 +129,13 @@ struct pigs_ctx {
     unsigned long long *d_xch = nullptr;    // exchange buffer of the cooperating workgroups
     int        *h_cm_err = nullptr;         // (pinned, device-visible) set by a workgroup whose partner never answered
     unsigned int cm_seq = 1;                // sequence tags of the exchange: advanced by every launch
+    bool        counted = false;            // in g_live_ctx
     bool        sampler_ready = false;
 };
+
+// live contexts per device of this process: the TranslateChain helpers (pigs_cm.hip) assume that the walkers of ONE
+// context have the chip to themselves
+static std::atomic<int> g_live_ctx[64];
 
 static int check_ctx(pigs_ctx *c)
 {
@@ -243,6 +249,8 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
         pigs_ctx_destroy(c);
         return rc;
     }
+    c->counted = true;
+    g_live_ctx[device_id & 63].fetch_add(1);
     *out = c;
     return PIGS_OK;
 }
@@ -250,6 +258,7 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
 int pigs_ctx_destroy(pigs_ctx *c)
 {
     if (!c) return PIGS_OK;
+    if (c->counted) { g_live_ctx[c->device & 63].fetch_sub(1); c->counted = false; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { pigs_comm_destroy(c->comm); c->comm = nullptr; }
@@ -697,7 +706,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     // TranslateChain -- the one arithmetic-bound stage -- goes to H cooperating workgroups per walker (pigs_cm.hip) while
     // the chip has H >= 2 CUs per walker (bit-identical trajectory whatever H): open / close attempt, that kernel, the rest.
     int H = 0;
-    if (c->cm_split != 0 && sp.do_cm) {
+    if (c->cm_split != 0 && sp.do_cm && g_live_ctx[c->device & 63].load() == 1) {
         H = cm_helpers(c->P, sp, c->n_cu);                    // what the chip holds (0: the kernel does not apply)
         if (c->cm_split > 0) H = H < c->cm_split ? H : c->cm_split;      // on request: also H = 1
         else if (H < 2) H = 0;
@@ -718,14 +727,10 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
         HIPCHK(hipHostGetDevicePointer((void **)&d_err, c->h_cm_err, 0));
         const hipError_t e = launch_cm(c->P, sp, H, c->cm_seq, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
                                        c->d_worm, c->d_xch, d_err, c->stream);
-        if (e == hipErrorCooperativeLaunchTooLarge) {        // the chip is shared: the one-workgroup form takes the moves
-            (void)hipGetLastError();
-        } else {
-            HIPCHK(e);
-            c->cm_seq += (unsigned int)c->P.Np + 1;
-            sp.do_cm = 0;
-        }
-        cm_done = true;                                       // (the open / close attempt ran)
+        HIPCHK(e);
+        c->cm_seq += (unsigned int)c->P.Np + 1;
+        sp.do_cm = 0;
+        cm_done = true;                                       // (the open / close attempt ran as well)
     }
     const bool need_split = !c->P.trap && !sp.staging && sp.Nlev > 4;
     const bool split = (c->sweep_split || need_split) && diag_supported(c->P, sp);

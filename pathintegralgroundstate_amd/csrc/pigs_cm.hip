@@ -17,9 +17,12 @@
 //   * an accepted move is committed by every workgroup to its own beads.  A workgroup only ever reads slices of its own
 //     range (the pair action is local in imaginary time), so the worldline needs no cross-workgroup visibility
 //     inside the launch.
-// The launch is cooperative (hipLaunchCooperativeKernel): all H x W workgroups are resident together or the launch is
-// refused, so the polling loops cannot wait for a workgroup that never started; they are bounded all the same and
-// report through an error word the host checks at its next synchronisation.
+// Residency: H x W <= CUs and a workgroup fills a CU's LDS (table image + per-wave scratch), so on a chip this context
+// has to itself -- the library checks: one live context per device in the process -- every workgroup gets a CU of its
+// own at once and the polling loops wait microseconds.  They are bounded all the same (another PROCESS may crowd the
+// chip): a workgroup that waits in vain gives up after seconds and raises an error word the host checks at its next
+// synchronisation.  (hipLaunchCooperativeKernel would state the residency requirement to the runtime; it is not used:
+// same speed, and rocprofv3 of this ROCm release segfaults at exit after a cooperative launch.)
 #include "pigs_device.h"
 #include "pigs_k1_device.h"
 #include "pigs_kernels.h"
@@ -242,8 +245,8 @@ hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned 
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cm<D, NT>),                                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
         if (e == hipSuccess)                                                                                       \
-            e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_cm<D, NT>), dim3(P.nW * H), dim3(NT),  \
-                                           args, (unsigned int)lds, st);                                           \
+            e = hipLaunchKernel(reinterpret_cast<const void *>(k_cm<D, NT>), dim3(P.nW * H), dim3(NT), args,       \
+                                (unsigned int)lds, st);                                                            \
     } while (0)
     if (nt == 1024) { if (P.dim == 1) CALLC(1, 1024); else if (P.dim == 2) CALLC(2, 1024); else CALLC(3, 1024); }
     else            { if (P.dim == 1) CALLC(1, 512); else if (P.dim == 2) CALLC(2, 512); else CALLC(3, 512); }
