@@ -27,7 +27,8 @@ def main():
     ks = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     for v in [int(x) for x in os.environ.get("VARIANTS", "2,8,11").split(",")]:
         ctx.set_tuning("k1_variant", v)
-        for n in (16, 256, 1024, 4096, 8192, 12288, 16384, n_all):
+        sizes = [int(x) for x in os.environ['SIZES'].split(',')] if os.environ.get('SIZES') else (16, 256, 1024, 4096, 8192, 12288, 16384, n_all)
+        for n in sizes:
             w, ip, ib, xn, xo = d
             for _ in range(5):
                 ctx.delta_action_batch_dev(n, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(), out.data_ptr())
