@@ -229,6 +229,16 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # what a kernel that ONLY reads the resident worldlines reaches on this chip (measurement aid of the library): context
+    # for `frac`, which stays priced against the guide's 8 TB/s
+    stream_read = None
+    try:
+        sb, st_s = ctx.stream_read(50)
+        stream_read = {"GBs": sb / st_s / 1e9, "bytes_per_pass": sb, "us_per_pass": 1e6 * st_s,
+                       "kernel": "pigs::k_stream_read (plain double2 loads of the same %d resident walkers)" % W}
+    except Exception as e:                                   # noqa: BLE001 -- informative only
+        stream_read = {"error": str(e)}
+
     # ---- the same stage on 3x the walkers: 380 MB of worldlines, beyond the 256 MiB Infinity Cache ----------------
     large = None
     if args.large_walkers > 0:
@@ -274,6 +284,11 @@ def main():
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytesL / (msL * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "steps": nstepL, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
                                           "than the 256 MiB Infinity Cache, so every slice comes from HBM"}
+        try:
+            sb, st_s = ctxL.stream_read(30)
+            large["streaming_read_same_bytes"] = {"GBs": sb / st_s / 1e9, "bytes_per_pass": sb, "us_per_pass": 1e6 * st_s}
+        except Exception as e:                               # noqa: BLE001 -- informative only
+            large["streaming_read_same_bytes"] = {"error": str(e)}
         ctxL.close()
         del dL, oL
 
@@ -424,7 +439,8 @@ def main():
                          "kernel_source": "library dispatch rule (pigs_k1.hip launch_delta_action); confirmed by "
                                           "profiles/r02_bench_kernel_stats.csv",
                          "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "streaming_read_same_bytes": stream_read},
             "roofline_large": large,
             "cpu_baseline": cpu,
             "kernel_only_evals_per_s": pair_evals_per_step / (kern_ms * 1e-3),

@@ -95,6 +95,10 @@ int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */
 int pigs_selftest_fastmath(pigs_ctx *ctx, int32_t blocks, int32_t iters, uint64_t bad[4]);
+/* Measurement aid: `reps` plain streaming reads of the context's resident worldlines (the bytes a full-chain Delta-S
+ * stage reads) by a kernel that does nothing else; *bytes per pass, *seconds per pass (HIP events on the context's
+ * stream).  bench.py quotes it next to K1's roofline as the rate this chip's memory system delivers to a reader. */
+int pigs_selftest_stream_read(pigs_ctx *ctx, int32_t reps, double *bytes, double *seconds);
 
 /* Host-side table fill: JastrowTable / PotentialTable (vpi_mod.f90:84-145) over
  * LogPsi / Potential (system_mod.f90:38-66,136-182), including dr = rmax/real(Nmax-1)

@@ -249,6 +249,10 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
         pigs_ctx_destroy(c);
         return rc;
     }
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, device_id) == hipSuccess && pr.multiProcessorCount > 0) c->n_cu = pr.multiProcessorCount;
+    }
     c->counted = true;
     g_live_ctx[device_id & 63].fetch_add(1);
     *out = c;
@@ -344,6 +348,29 @@ int pigs_selftest_fastmath(pigs_ctx *c, int32_t blocks, int32_t iters, uint64_t 
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipFree(d));
     for (int i = 0; i < 4; ++i) bad[i] = h[i];
+    return PIGS_OK;
+}
+
+int pigs_selftest_stream_read(pigs_ctx *c, int32_t reps, double *bytes, double *seconds)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!bytes || !seconds || reps < 1) return fail(PIGS_ERR_ARG, "bad arguments");
+    const size_t nd = c->path_doubles * (size_t)c->n_walkers;
+    double *sink = nullptr;
+    HIPCHK(hipMalloc((void **)&sink, sizeof(double)));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; ++r) HIPCHK(launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(hipFree(sink));
+    *bytes = (double)(nd * sizeof(double));
+    *seconds = 1e-3 * (double)ms / reps;
     return PIGS_OK;
 }
 

@@ -85,6 +85,7 @@ hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned 
                      unsigned long long *xch, int *err, hipStream_t st);
 int sweep_form(const DevParams &P, const SweepParams &sp, int threads);   // workgroup size launch_sweep uses for a request
 
+hipError_t launch_stream_read(const double *a, size_t doubles, int blocks, double *sink, hipStream_t st);
 hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
                                     unsigned long long *d_bad, hipStream_t st);
 

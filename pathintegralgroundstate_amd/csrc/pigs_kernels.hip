@@ -597,4 +597,25 @@ hipError_t launch_unpack(const DevParams &P, const double *paths, double *raw, i
     return hipGetLastError();
 }
 
+// ---- measurement aid: a plain streaming read of the resident worldlines (what a kernel that only READS the bytes K1
+// reads would take): double2 per lane, four requests in flight, one 1024-thread workgroup per CU (pigs_selftest_stream_read)
+__global__ __launch_bounds__(1024) void k_stream_read(const double2 *__restrict__ a, size_t n, double *sink)
+{
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const double2 x0 = a[i], x1 = a[i + stride], x2 = a[i + 2 * stride], x3 = a[i + 3 * stride];
+        s += ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+    }
+    for (; i < n; i += stride) { const double2 x = a[i]; s += x.x + x.y; }
+    if (s == 1.2345e-300) sink[0] = s;                                // (never: keeps the loads)
+}
+
+hipError_t launch_stream_read(const double *a, size_t doubles, int blocks, double *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(1024), 0, st, reinterpret_cast<const double2 *>(a), doubles / 2, sink);
+    return hipGetLastError();
+}
+
 } // namespace pigs

@@ -283,3 +283,4 @@ int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n)
     return PIGS_OK;
 }
 int pigs_selftest_fastmath(pigs_ctx *c, int32_t b, int32_t i, uint64_t bad[4]) { (void)c; (void)b; (void)i; memset(bad, 0, 32); return PIGS_OK; }
+int pigs_selftest_stream_read(pigs_ctx *c, int32_t reps, double *bytes, double *seconds) { (void)c; (void)reps; *bytes = 0.0; *seconds = 1.0; return PIGS_OK; }

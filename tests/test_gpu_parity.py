@@ -115,6 +115,20 @@ def test_short_division_and_sqrt_are_exact(gpu_lib):
     assert n == 2048 * 256 * 512 and bad == [0, 0, 0, 0], bad
 
 
+def test_stream_read_measurement_aid(gpu_lib):
+    """pigs_selftest_stream_read: bytes per pass = the resident worldlines (padded SoA), a positive time, and the
+    worldlines are still what was uploaded."""
+    t = load_golden("tables_he4_n256")
+    cfg = config_from_golden(t)
+    rng = np.random.default_rng(3)
+    P = rng.uniform(-1, 1, (4, cfg.M, cfg.Np, cfg.dim))
+    with gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=4) as ctx:
+        ctx.upload_all(P)
+        nbytes, sec = ctx.stream_read(5)
+        assert nbytes >= P.nbytes and nbytes < 1.1 * P.nbytes and 0 < sec < 1e-2
+        assert np.array_equal(ctx.download_all(), P)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 7, 8, 12, 13, 14])
 @pytest.mark.parametrize("name", ["he4_n64_eq", "he4_n64_rnd", "pbc2d_n16", "trap3d_n8"])
 def test_every_k1_variant_vs_golden(gpu_lib, name, variant):
