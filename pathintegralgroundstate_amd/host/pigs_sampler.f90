@@ -66,6 +66,9 @@ module pigs_sampler
      ! ---- statistics
      integer(8) :: n_eval_items = 0, n_eval_calls = 0
      real(8)    :: t_eval = 0.d0         ! wall seconds spent inside the batched Delta-S calls
+     ! ---- host threads for the per-walker loops of a stage (proposals, decisions): walkers are independent there --
+     ! own random stream, own item slots (plan_items), own rows of the mirror -- so the threads change no result
+     integer    :: nthr = 1
   end type sampler_t
 
 contains
@@ -83,6 +86,7 @@ contains
     s%dim = dim; s%Np = Np; s%Nb = Nb; s%W = W; s%trap = trap
     s%dt = dt; s%density = density; s%CWorm = CWorm; s%ctx = ctx
     s%pi = acos(-1.d0)
+    s%nthr = host_threads(W)
     s%n_items = 0; s%cap = 0; s%n_commit = 0; s%ccap = 0
     s%n_eval_items = 0; s%n_eval_calls = 0; s%t_eval = 0.d0
     do k=1,dim
@@ -97,6 +101,26 @@ contains
     call grow_items(s,max(64,W*(2*Nb+1)))
     call grow_commit(s,max(64,2*W*(2*Nb+1)))
   end subroutine sampler_init
+
+  ! threads for the per-walker loops: PIGS_HOST_THREADS, else what OpenMP offers to this (possibly nested) level, at most
+  ! 16 and at least 128 walkers per thread: a stage's host work is ~0.4 us per walker and a stage has four fork-joins of
+  ! several us each -- measured at 128 walkers (N=256, 161 beads): 2.7 s per block on one thread, 3.0 s on eight
+  function host_threads(W) result(n)
+    !$ use omp_lib
+    integer, intent(in) :: W
+    integer :: n,ios
+    character(len=32) :: ev
+    n = 1
+    !$ n = min(16,omp_get_max_threads())
+    n = min(n,W/128)
+    call get_environment_variable('PIGS_HOST_THREADS',ev)
+    if (len_trim(ev)>0) then                                  ! explicit request: any count up to one thread per walker
+       read(ev,*,iostat=ios) n
+       if (ios/=0) n = 1
+       n = min(n,W)
+    end if
+    n = max(1,n)
+  end function host_threads
 
   subroutine sampler_free(s)
     type(sampler_t), intent(inout) :: s
@@ -461,6 +485,7 @@ contains
     call begin_stage(s)
     where (active) s%want = 2*s%Nb+1
     call plan_items(s)
+    !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w,ip,k,ib,dx,xold,xnew)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = ip_of(w)
@@ -479,6 +504,7 @@ contains
        end do
        s%S0(w) = 0.d0
     end do
+    !$omp end parallel do
     call evaluate(s)
     call settle_simple(s,ip_of,active,accepted,0)
   end subroutine mv_translate
@@ -491,6 +517,7 @@ contains
     logical, intent(in)    :: active(s%W)
     integer, intent(inout) :: accepted(s%W)
     integer :: w,ii
+    !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w,ii)
     do w=1,s%W
        s%alive(w) = active(w)
        if (.not. active(w)) cycle
@@ -498,6 +525,7 @@ contains
        call save_chain(s,w,ip_of(w),ii,ii+2**level)
        s%aux_i(w) = level
     end do
+    !$omp end parallel do
     call run_levels(s,ip_of,active,accepted)
   end subroutine mv_bisection
 
@@ -520,18 +548,22 @@ contains
        end do
        call plan_items(s)
        if (s%n_items==0) exit
+       !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w)
        do w=1,s%W
           if (.not. s%alive(w)) cycle
           if (ilev>s%aux_i(w)) cycle
           call gen_bisection_level(s,w,ip_of(w),s%seg_i(w),s%aux_i(w),ilev)
        end do
+       !$omp end parallel do
        call evaluate(s)
+       !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w,t)
        do w=1,s%W
           if (.not. s%alive(w)) cycle
           if (ilev>s%aux_i(w)) cycle
           t = sum_items(s,w,0.d0)
           if (.not. metropolis(s,w,-t)) s%alive(w) = .false.
        end do
+       !$omp end parallel do
     end do
     do w=1,s%W
        if (.not. active(w)) cycle
@@ -557,6 +589,7 @@ contains
     call begin_stage(s)
     where (active) s%want = 1
     call plan_items(s)
+    !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w,nl,ii,ie)
     do w=1,s%W
        s%alive(w) = active(w)
        if (.not. active(w)) cycle
@@ -575,12 +608,15 @@ contains
           call gen_end_guess(s,w,ip_of(w),ie,ii,2**nl,-1,1.d0)
        end if
     end do
+    !$omp end parallel do
     call evaluate(s)
+    !$omp parallel do schedule(static) num_threads(s%nthr) if(s%nthr>1) default(shared) private(w,t)
     do w=1,s%W
        if (.not. active(w)) cycle
        t = sum_items(s,w,0.d0)
        if (.not. metropolis(s,w,-t)) s%alive(w) = .false.
     end do
+    !$omp end parallel do
     call run_levels(s,ip_of,active,accepted)
   end subroutine mv_end_bisection
 

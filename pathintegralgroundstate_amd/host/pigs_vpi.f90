@@ -246,6 +246,7 @@ contains
   ctx = ctxs(ish)
 
   call sampler_init(s,dim,Np,Nb,NW,trap,dt,density,CWorm,Lbox(1:dim),ctx)
+  if (ish==1 .and. .not. device_sampler) print '(a,i6)','  > host threads per stage:',s%nthr
   ep%dim = dim; ep%Np = Np; ep%Nbin = Nbin; ep%Nk = Nk; ep%Npw = Npw; ep%trap = trap
   ep%rcut2 = rcut2; ep%rbin = rbin; ep%pi = pi; ep%CWorm = CWorm
   ep%Lbox = Lbox; ep%LboxHalf = 0.5d0*Lbox; ep%qbin = 2.d0*pi/Lbox

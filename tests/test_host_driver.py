@@ -147,6 +147,23 @@ def test_own_checkpoint_round_trip(exe, tmp_path):
     assert lines[0].strip() == ".False." and len([l for l in lines if l.strip()]) == 3 + 16 * 17 + 2
 
 
+def test_host_threads_change_nothing(exe, tmp_path):
+    """The per-walker loops of a stage (proposal generation, Metropolis decisions) run on OpenMP threads in the host-driven
+    sampler: walkers own their random streams, item slots and mirror rows, so every file is the same byte for byte."""
+    base = open(os.path.join(RUNS, "he4_stock_short", "vpi.in")).read()
+    outs = []
+    for n in (1, 4):
+        d = tmp_path / f"t{n}"
+        d.mkdir()
+        run_pigs_vpi(exe, base + "&gpu\n n_walkers = 6, device = 0\n/\n", str(d), env=dict(os.environ, PIGS_HOST_THREADS=str(n)))
+        outs.append(d)
+    assert f"host threads per stage:{4:6d}" in open(outs[1] / "stdout.txt").read()
+    assert same_bits(np.fromfile(outs[0] / "worldlines_final.bin"), np.fromfile(outs[1] / "worldlines_final.bin"))
+    names = FILES + [f"e_vpi.w{w:04d}.hex" for w in range(6)] + [f"e_vpi.w{w:04d}.out" for w in range(6)]
+    for f in names:
+        assert open(outs[0] / f, "rb").read() == open(outs[1] / f, "rb").read(), f
+
+
 @pytest.mark.parametrize("G", [2, 3])
 def test_walkers_sharded_over_contexts_equal_one_context(exe, G, tmp_path):
     """&gpu n_gpus = G (BASELINE config 4's structure: walkers in contiguous shards, one context + one host thread per
