@@ -338,6 +338,17 @@ __device__ __forceinline__ double read_lane(double v, int lane)
     return u.d;
 }
 
+// value of lane (i + N) of the same row of 16 lanes (DPP row_shl:N; 0 beyond the row): no LDS round trip
+template <int N>
+__device__ __forceinline__ double row_shl(double x)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = x;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x100 + N, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x100 + N, 0xf, 0xf, true);
+    return r.d;
+}
+
 // ---- Chin weights (global_mod.f90:19-72) -------------------------------------------
 __host__ __device__ inline double green_function(int opt, int ib, int Nb, double dt, double Pot, double F2)
 {

@@ -67,17 +67,6 @@ __device__ __forceinline__ void lds_barrier()
 }
 __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// value of lane (i + N) of the same row of 16 lanes (DPP row_shl:N; 0 beyond the row): no LDS round trip
-template <int N>
-__device__ __forceinline__ double row_shl(double x)
-{
-    union { double d; int i[2]; } u, r;
-    u.d = x;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x100 + N, 0xf, 0xf, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x100 + N, 0xf, 0xf, true);
-    return r.d;
-}
-
 struct DiagLds {
     size_t mt, ctl, Gc, Lc, pc0, pc1, dS, cn, gbuf, sxn, sxo, sb, dxs, sgn, sgb, tots, red, tab, total;
 };

@@ -299,6 +299,32 @@ __device__ __forceinline__ double item_finish_split(const DevParams &P, int b, i
     return -dPsi + green_function_action(b, P.Nb, P.dt, dPot, dF2);
 }
 
+// the same by the lanes of ONE wave for up to 8 items at once: lane = item * 8 + column adds its column over the passes
+// (in pass order, as above), the neighbours' columns come by DPP row shifts (no LDS round trip, no loop on one lane);
+// Delta S of item i is returned in lane 8 i.  Same operations in the same order as item_finish_split: same bits.
+template <int DIM>
+__device__ __forceinline__ double item_finish_split_lanes(const DevParams &P, int n, const int *ibs, int npass,
+                                                          const double *tot, int lane)
+{
+    const bool on = lane < n * 8;
+    const int i = on ? lane >> 3 : 0;
+    double cs = 0.0;
+    {
+        const double *T = tot + (size_t)i * npass * 8 + (lane & 7);
+        for (int m = 0; m < npass; ++m) cs = cs + (on ? T[m * 8] : 0.0);
+    }
+    const int b = ibs[i];
+    const bool odd  = (b & 1) != 0;
+    const bool endb = (b == 0) || (b == 2 * P.Nb);
+    const double d01 = cs - row_shl<1>(cs);                           // column 0: DeltaPot; column 2: PsiNew - PsiOld
+    const double sq  = cs * cs;
+    double f2 = sq;                                                   // column 2: |Fnew|^2, column 5: |Fold|^2 (DIM terms, in order)
+    if (DIM > 1) f2 = f2 + row_shl<1>(sq);
+    if (DIM > 2) f2 = f2 + row_shl<2>(sq);
+    const double fn2 = row_shl<2>(f2), fo2 = row_shl<5>(f2), dps = row_shl<2>(d01);
+    return -(endb ? dps : 0.0) + green_function_action(b, P.Nb, P.dt, d01, odd ? fn2 - fo2 : 0.0);
+}
+
 template <int DIM, bool TRAP, typename VTab>
 __device__ __forceinline__ void item_eval_prefetch(const DevParams &P, VTab VT, const double *__restrict__ WF,
                                                    const double *__restrict__ S, int p, int b, const double (&xn)[DIM],
