@@ -300,8 +300,8 @@ def main():
         mcfg = SystemConfig(dim=3, Np=args.np, Nb=args.nb, density=0.365, dt=5e-3, Rm=1.2, Nlev=4, Nstag=5,
                             Lstag=32, CMFreq=1, delta_cm=0.12)
         ctx.sampler_init(Nlev=mcfg.Nlev, Nstag=mcfg.Nstag, CMFreq=1, Lstag=min(32, args.nb), delta_cm=mcfg.delta_cm_eff)
-        if args.same_device and world > 1:      # rehearsal: several processes on one chip -- no helper workgroups (pigs_cm.hip)
-            ctx.set_tuning("cm_split", 0)
+        if args.same_device and world > 1:      # rehearsal: several processes on one chip -- no cooperating workgroups (pigs_cm.hip)
+            ctx.set_tuning("cm_split", 1)
         for w in range(W):
             ctx.sampler_seed(w, 1982 + rank * W + w)
         acc0 = ctx.sampler_counters()

@@ -87,10 +87,10 @@ int pigs_stream(pigs_ctx *ctx, void **hip_stream);
  *      for Nlev > 4.
  *   "cm_split": the TranslateChain moves of a periodic system (Np <= 256) by H cooperating workgroups per walker
  *      (pigs_cm.hip: bead ranges on H CUs, Delta S exchanged and added in bead order -- the trajectory does not depend
- *      on H, bit for bit).  -1 (default): H = min(4, CUs / walkers) when that is >= 2; 0: inside the sweep kernel;
- *      1..4: at most that many.  Used only while the context is the process's only one on its device; a cooperating
- *      workgroup that waits in vain (several PROCESSES crowding one chip: set 0 there) gives up after seconds and the
- *      next pigs_sync returns PIGS_ERR_HIP. */
+ *      on H, bit for bit).  -1 (default): H = min(4, CUs / walkers), at least 1 (one workgroup per walker exchanges
+ *      nothing and is still the faster TranslateChain); 0: inside the sweep kernel; 1..4: at most that many.  H > 1 only
+ *      while the context is the process's only one on its device; a cooperating workgroup that waits in vain (several
+ *      PROCESSES crowding one chip: set 1 there) gives up after seconds and the next pigs_sync returns PIGS_ERR_HIP. */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */

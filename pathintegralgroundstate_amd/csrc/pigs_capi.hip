@@ -730,13 +730,17 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
     // vs 56.5 ms per MC step (profiles/r02_k6_stage_machine.txt), so the stage machine runs only where the other form
     // cannot, or on request (pigs_set_tuning "sweep_split" = 1).
     //
-    // TranslateChain -- the one arithmetic-bound stage -- goes to H cooperating workgroups per walker (pigs_cm.hip) while
-    // the chip has H >= 2 CUs per walker (bit-identical trajectory whatever H): open / close attempt, that kernel, the rest.
+    // TranslateChain -- the one arithmetic-bound stage -- goes to its own kernel (pigs_cm.hip): H cooperating workgroups
+    // per walker while the chip has H >= 2 CUs per walker, one otherwise (bit-identical trajectory whatever H): open /
+    // close attempt, that kernel, the rest.
     int H = 0;
-    if (c->cm_split != 0 && sp.do_cm && g_live_ctx[c->device & 63].load() == 1) {
+    if (c->cm_split != 0 && sp.do_cm) {
         H = cm_helpers(c->P, sp, c->n_cu);                    // what the chip holds (0: the kernel does not apply)
-        if (c->cm_split > 0) H = H < c->cm_split ? H : c->cm_split;      // on request: also H = 1
-        else if (H < 2) H = 0;
+        if (c->cm_split > 0 && H > c->cm_split) H = c->cm_split;
+        // cooperating workgroups wait for each other: only while this context has the chip to itself.  One workgroup per
+        // walker (H = 1) exchanges nothing and is still the faster TranslateChain (sixteen waves on the LDS table image:
+        // 46.8 -> 44.8 ms per MC step at 256 walkers, 95 -> 74 ms at 512, where the sweep kernel runs its 4-wave form)
+        if (H > 1 && g_live_ctx[c->device & 63].load() != 1) H = 1;
     }
     bool cm_done = false;
     if (H >= 1) {
@@ -1020,9 +1024,9 @@ int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks)
         auto g = std::make_shared<HostGroup>();
         g->n = nranks;
         g->slot.resize(nranks);
-        // (several contexts share one chip here: TranslateChain stays inside each walker's own workgroup -- the helpers
-        // of pigs_cm.hip assume the walkers of ONE context have the chip to themselves)
-        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; ctxs[i]->cm_split = 0; }
+        // (several contexts share one chip here: one workgroup per walker in pigs_cm.hip -- cooperating workgroups assume
+        // that the walkers of ONE context have the chip to themselves)
+        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; ctxs[i]->cm_split = 1; }
         return PIGS_OK;
     }
     const char *err = pigs_comm_create_all(comms.data(), nranks, devs.data());

@@ -209,6 +209,17 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
     }
 }
 
+// workgroup size for H ranges per walker: sixteen waves (four per SIMD, 128 registers each) where their scratch fits next
+// to the table image, eight otherwise; a thread per coordinate of the range's beads; 0: does not fit
+static int cm_threads(const DevParams &P, int H)
+{
+    static const int want = getenv("PIGS_CM_THREADS") ? atoi(getenv("PIGS_CM_THREADS")) : 1024;
+    const int rows = (cm_range(P.M, H, 1) + 1) * P.dim;
+    if (want >= 1024 && cm_layout(P, 16, H).total <= 160 * 1024 && rows <= 1024) return 1024;
+    if (cm_layout(P, 8, H).total <= 160 * 1024 && rows <= 512) return 512;
+    return 0;
+}
+
 // the most workgroups per walker the chip holds together (1..4), 0 where the kernel does not apply: trapped systems,
 // more than 256 particles (four 64-partner passes per bead), a step without TranslateChain, a worldline beyond the ring
 // of random words or the LDS
@@ -219,8 +230,7 @@ int cm_helpers(const DevParams &P, const SweepParams &sp, int n_cu)
     int H = n_cu / P.nW;
     if (H > 4) H = 4;
     if (H < 1) H = 1;
-    auto fits = [&](int h) { return cm_layout(P, 8, h).total <= 160 * 1024 && (cm_range(P.M, h, 1) + 1) * P.dim <= 512; };   // (the 8-wave form)
-    if (!fits(H)) return 0;                      // (more workgroups = shorter ranges: if H does not fit, fewer do not either)
+    if (cm_threads(P, H) == 0) return 0;         // (more workgroups = shorter ranges: if H does not fit, fewer do not either)
     return H;
 }
 
@@ -231,11 +241,9 @@ hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned 
                      unsigned long long *xch, int *err, hipStream_t st)
 {
     if (H < 1 || H > 4 || P.trap || (P.Nmax & 1) || P.Np > 256) return hipErrorInvalidValue;
-    // sixteen waves (four per SIMD, 128 registers each) where their scratch fits next to the table image, eight otherwise
-    static const int want = getenv("PIGS_CM_THREADS") ? atoi(getenv("PIGS_CM_THREADS")) : 1024;
-    const int nt = (want >= 1024 && cm_layout(P, 16, H).total <= 160 * 1024) ? 1024 : 512;
+    const int nt = cm_threads(P, H);
+    if (nt == 0) return hipErrorInvalidValue;
     const size_t lds = cm_layout(P, nt / kWave, H).total;
-    if (lds > 160 * 1024 || (cm_range(P.M, H, 1) + 1) * P.dim > 512) return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     DevParams Pk = P;
     SweepParams spk = sp;
