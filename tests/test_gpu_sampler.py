@@ -254,6 +254,56 @@ def test_sampler_forms_agree(gpu_lib, oracle):
     assert np.array_equal(got[4][:, :, 0], ref[4][:, :, 0])
 
 
+def test_sampler_forms_agree_on_long_chains(gpu_lib, oracle):
+    """The same on chains long enough for everything the 8-wave form adds (33 and 81 beads, worm sector, 120 MC steps =
+    ~3 10^5 stages per walker): speculative proposals of the next bisection level, TranslateChain on several CUs per walker
+    -- against the 4-wave form, which has neither, and the stage-machine kernel.  Every decision identical, worldlines to
+    rounding: rare paths (a window of candidates that does not suffice, a stream refill between stages, a uniform of the
+    accept-without-draw kind) would show up as a different generator state."""
+    from oracle.pyoracle import System
+    for Np, Nb, dens in ((48, 16, 0.3), (130, 40, 0.365)):
+        cfg = SystemConfig(dim=3, Np=Np, Nb=Nb, density=dens, dt=5e-3, Rm=1.2, Nlev=4, Nstag=2, Lstag=8, CMFreq=1,
+                           delta_cm=0.3, CWorm=0.5, Nobdm=3, Nbin=50, Npw=0)
+        S = System(dim=3, Np=Np, Nb=Nb, density=dens, dt=5e-3, Rm=1.2)
+        VT, WF = gpu_lib.build_tables(cfg)
+        W = 3
+        results = {}
+        for form in ("8 waves", "4 waves", "stage machine", "8 waves, TranslateChain in the sweep kernel"):
+            ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+            ctx.sampler_init(CWorm=cfg.CWorm, swapping=True, Nobdm=cfg.Nobdm, Nbin=cfg.Nbin, Npw=0)
+            if form == "4 waves":
+                ctx.set_tuning("sweep_threads", 256)
+            if form == "stage machine":
+                ctx.set_tuning("sweep_split", 1)
+            if form.endswith("sweep kernel"):
+                ctx.set_tuning("cm_split", 0)
+            Paths = []
+            for w in range(W):
+                P, g = oracle.init_path(S, 900 + w)
+                Paths.append(P)
+                ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+            Paths = np.stack(Paths)
+            ctx.upload_all(Paths)
+            xe = np.repeat(Paths[:, cfg.Nb, cfg.Np - 1][:, None, :], 2, axis=1)
+            ctx.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe)
+            for istep in range(1, 121):
+                ctx.sampler_step(istep)
+            results[form] = (ctx.download_all(), ctx.sampler_counters16(), [ctx.sampler_get_rng(w) for w in range(W)],
+                             ctx.sampler_get_worm(), ctx.sampler_nrho())
+            ctx.close()
+        ref = results["8 waves"]
+        assert ref[1][:, 0].min() > 0 and ref[1][:, 3].min() > 0           # TranslateChain and Bisection moves were accepted
+        L = np.asarray(cfg.Lbox[:cfg.dim])
+        for form, got in results.items():
+            d = got[0] - ref[0]
+            assert np.max(np.abs(d - L * np.round(d / L))) < 1e-9, form
+            assert np.array_equal(got[1], ref[1]), form
+            for a, b in zip(got[2], ref[2]):
+                assert a[0] == b[0] and np.array_equal(np.asarray(a[1]), np.asarray(b[1])), form
+            assert np.array_equal(got[3][0], ref[3][0]) and np.array_equal(got[3][1], ref[3][1]), form
+            assert np.array_equal(got[4][:, :, 0], ref[4][:, :, 0]), form
+
+
 def _untemper(y):
     """Inverse of MT19937's tempering: the raw state word whose output is y."""
     y ^= y >> 18
