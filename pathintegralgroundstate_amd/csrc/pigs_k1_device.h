@@ -93,31 +93,29 @@ template <int DIM, int CLS>
 __device__ __forceinline__ void finish_item(const DevParams &P, int lane, int b, const Acc<DIM, CLS> &A,
                                             double *red, double *out, double *parts)
 {
+    // after the reduction lane q holds the total of column q; the neighbours' columns reach lane 0 by DPP row shifts
+    // (no v_readlane -> scalar -> vector round trips); the results below are meaningful in lane 0 only
     double dPot, dF2 = 0.0, dPsi = 0.0;
     if (CLS == CLS_ODD) {
         double v[8] = {A.potN, A.potO, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < DIM; ++k) { v[2 + k] = A.fN[k]; v[5 + k] = A.fO[k]; }
         const double t = wave_reduce_lds<8>(v, red, lane);
-        double fn2 = 0.0, fo2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) {
-            const double a = read_lane(t, 2 + k);
-            const double c = read_lane(t, 5 + k);
-            fn2 = fn2 + a * a;                                      // vpi_mod.f90:2831-2832
-            fo2 = fo2 + c * c;
-        }
-        dPot = read_lane(t, 0) - read_lane(t, 1);                   // :2838
-        dF2  = fn2 - fo2;                                           // :2835
+        const double sq = t * t;
+        double f2 = sq;                                             // lane 2: |Fnew|^2, lane 5: |Fold|^2 (vpi_mod.f90:2831-2832)
+        if (DIM > 1) f2 = f2 + row_shl<1>(sq);
+        if (DIM > 2) f2 = f2 + row_shl<2>(sq);
+        dPot = t - row_shl<1>(t);                                   // :2838
+        dF2  = row_shl<2>(f2) - row_shl<5>(f2);                     // :2835
     } else if (CLS == CLS_END) {
         const double v[4] = {A.potN, A.potO, A.psiN, A.psiO};
         const double t = wave_reduce_lds<4>(v, red, lane);
-        dPot = read_lane(t, 0) - read_lane(t, 1);
-        dPsi = read_lane(t, 2) - read_lane(t, 3);                   // :2653
+        dPot = t - row_shl<1>(t);
+        dPsi = row_shl<2>(dPot);                                    // lane 2: PsiNew - PsiOld (:2653)
     } else {
         const double v[2] = {A.potN, A.potO};
         const double t = wave_reduce_lds<2>(v, red, lane);
-        dPot = read_lane(t, 0) - read_lane(t, 1);
+        dPot = t - row_shl<1>(t);
     }
     if (lane == 0) {
         *out = -dPsi + green_function_action(b, P.Nb, P.dt, dPot, dF2);      // :2527
