@@ -213,6 +213,7 @@ __host__ __device__ inline int sweep_tot_doubles(const DevParams &P, const Sweep
     const int ntot  = P.Np <= 256 ? 1 : (sp.Lstag > 8 ? sp.Lstag : 8);
     int n = P.Np;
     if (ntot * npass * 8 > n) n = ntot * npass * 8;
+    if (n < 64) n = 64;                                               // eight tasks of the lone end bead (new | old distance x four passes)
     return (n + 1) & ~1;
 }
 
