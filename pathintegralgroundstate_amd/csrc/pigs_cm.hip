@@ -76,7 +76,8 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
 
     const CmLds L = cm_layout(P, NW, H);
     uint32_t *mt  = reinterpret_cast<uint32_t *>(smem + L.mt);
-    int      *ctl = reinterpret_cast<int *>(smem + L.ctl);           // [0] accepted [1] uniforms taken by the question
+    int      *ctl = reinterpret_cast<int *>(smem + L.ctl);           // [0] accepted [1] uniforms taken by the question [2] an exchange
+                                                                     // timed out: nobody in this workgroup waits any more
     double   *pc  = reinterpret_cast<double *>(smem + L.pc);         // the particle's beads b0..b1-1, bead-major
     double   *dS  = reinterpret_cast<double *>(smem + L.dS);         // Delta S of every bead of the chain
     double   *red = reinterpret_cast<double *>(smem + L.red + (size_t)wid * kWaveLds);
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
         for (int t = tid; t < nimg / 2; t += NT) dst[t] = src[t];
     }
     const PipeTab VTp{lt + 2, P.Nmax + 3};
+    if (tid == 0) ctl[2] = 0;
     const bool isopen = sp.worm ? (int)worm[(size_t)w * kWormDoubles] != 0 : false;
     const int  pworm  = sp.worm ? (int)worm[(size_t)w * kWormDoubles + 1] - 1 : -1;
     __syncthreads();
@@ -118,7 +120,6 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
     __syncthreads();
 
     unsigned int n_try = 0, n_acc = 0;
-    bool dead = false;                                               // an exchange timed out: run on without waiting
     for (int p = pfirst; p < P.Np; ) {
         int pn = p + 1;
         if (isopen && pn == pworm) ++pn;
@@ -164,8 +165,12 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
                 for (;;) {
                     lo = __hip_atomic_load(&X[(size_t)b * 2],     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hi = __hip_atomic_load(&X[(size_t)b * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (((unsigned int)(lo >> 32) == tag && (unsigned int)(hi >> 32) == tag) || dead) break;
-                    if (++spins > kCmSpinLimit) { dead = true; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    if (((unsigned int)(lo >> 32) == tag && (unsigned int)(hi >> 32) == tag) || *(volatile int *)&ctl[2]) break;
+                    if (++spins > kCmSpinLimit) {                     // give up once, for the whole workgroup and the rest of the launch
+                        *(volatile int *)&ctl[2] = 1;
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 dS[b] = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
