@@ -722,6 +722,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
 {
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready) return fail(PIGS_ERR_ARG, "pigs_sampler_init first");
+    rc = check_cm(c); if (rc) return rc;                      // an earlier step's TranslateChain kernel gave up: stop here
     SweepParams sp = c->sweep;
     sp.do_cm = (istep % c->cm_freq) == 0;
     // Two forms of the diagonal bisection moves of a periodic system: inside the one-launch kernel (pigs_sampler.hip;
