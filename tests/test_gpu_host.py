@@ -241,7 +241,9 @@ def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     ("bis", "dim = 3, Np = 12, density = 0.3d0", "Nb = 10, Lstag = 6, Nlev = 2", "2.0d0, Nobdm = 45"),
     # chains long enough for the speculative proposals of the one-launch kernel (>= 24 beads) with 2 and 4 levels
     ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 2", "0.4d0"),
-    ("bis", "dim = 3, Np = 40, density = 0.25d0", "Nb = 24, Lstag = 10, Nlev = 4", "0.4d0")])
+    ("bis", "dim = 3, Np = 40, density = 0.25d0", "Nb = 24, Lstag = 10, Nlev = 4", "0.4d0"),
+    # three 64-partner passes per bead: the end bead's eight (new | old) x pass tasks, TranslateChain on four CUs per walker
+    ("bis", "dim = 3, Np = 130, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 4", "0.4d0")])
 def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, sampling, extra, samp, cworm):
     """No reference run exists for these shapes; the host-driven sampler (bit-identical to the reference wherever
     a fixture exists) is the yardstick: same input, three walkers, device_sampler = F and T must give the same
