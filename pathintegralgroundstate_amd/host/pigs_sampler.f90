@@ -347,9 +347,24 @@ contains
     end if
   end function metropolis
 
+  ! every mover takes its segment through save_chain before it touches a bead: the one place where a segment
+  ! that leaves the chain is caught (this flang has no -fcheck=bounds and its -fsanitize=address does not
+  ! instrument Fortran array accesses -- probed -- so the invariant is checked in the product build, always:
+  ! two integer compares per move)
+  subroutine need_beads(s,w,ip,ia,ie)
+    type(sampler_t), intent(in) :: s
+    integer, intent(in) :: w,ip,ia,ie
+    if (ia<0 .or. ie>2*s%Nb .or. ia>ie .or. ip<1 .or. ip>s%Np .or. w<1 .or. w>s%W) then
+       write (0,'(a,5i8,a,3i8)') ' pigs_sampler: segment outside the worldline (w,ip,ia,ie,2Nb): ',w,ip,ia,ie,2*s%Nb, &
+            & '  (W,Np,Nb): ',s%W,s%Np,s%Nb
+       error stop 3
+    end if
+  end subroutine need_beads
+
   subroutine save_chain(s,w,ip,ia,ie)
     type(sampler_t), intent(inout) :: s
     integer, intent(in) :: w,ip,ia,ie
+    call need_beads(s,w,ip,ia,ie)
     s%Old(:,ia:ie,w) = s%Path(:,ip,ia:ie,w)
     s%seg_i(w) = ia; s%seg_e(w) = ie
   end subroutine save_chain
@@ -359,6 +374,30 @@ contains
     integer, intent(in) :: w,ip
     s%Path(:,ip,s%seg_i(w):s%seg_e(w),w) = s%Old(:,s%seg_i(w):s%seg_e(w),w)
   end subroutine restore_chain
+
+  ! A worm-sector segment ii..ie that leaves the chain 0..2Nb (only possible when Lstag > Nb).  The reference then
+  ! indexes Path and OldChain outside their bounds (vpi_mod.f90:1853-1857 with ii = Nb-Ls < 0) and survives by
+  ! luck; with CWorm = 0 the proposal is never accepted whatever it read (quirk Q11: SumDeltaS starts at +Inf or
+  ! ends as NaN, exp() of it is never >= a uniform), so the only thing that reaches the rest of the run is the
+  ! position of the random stream.  Such a proposal is therefore DRAWN, NOT BUILT: no load, no store, no item.
+  logical function seg_outside(s,ii,ie)
+    type(sampler_t), intent(in) :: s
+    integer, intent(in) :: ii,ie
+    seg_outside = (ii<0 .or. ie>2*s%Nb .or. ii>ie)
+  end function seg_outside
+
+  ! the random numbers of a proposal with `ng` Gaussian draws followed by a Metropolis question that a uniform
+  ! decides (exp(-Inf) < 1: vpi_mod.f90:2029-2037) -- and nothing else
+  subroutine draw_only(s,w,ng)
+    type(sampler_t), intent(inout) :: s
+    integer, intent(in) :: w,ng
+    integer :: i
+    real(8) :: g,u
+    do i=1,ng
+       call mt_gauss(s%rng(w),g)
+    end do
+    u = mt_real(s%rng(w))
+  end subroutine draw_only
 
   ! ---- proposal generators (each writes the new bead into the host mirror and queues an item)
 
@@ -754,21 +793,29 @@ contains
     logical, intent(in)    :: active(s%W)
     integer, intent(inout) :: accepted(s%W)
     integer :: w,ii,ip
+    logical :: act(s%W)
     call begin_stage(s)
-    where (active) s%want = Lstag-1
+    ! a segment longer than the half chain (Lstag > Nb; refused by the front end in the worm sector, where the
+    ! reference indexes outside Path: see seg_outside) is drawn and rejected, never built
+    act = active .and. Lstag<=s%Nb
+    where (act) s%want = Lstag-1
     call plan_items(s)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = s%iworm(w)
        call select_half(s,w,ip,half)
        ii = int((s%Nb-Lstag+1)*mt_real(s%rng(w)))
+       if (.not. act(w)) then
+          call draw_only(s,w,(Lstag-1)*s%dim)
+          cycle
+       end if
        if (half==2) ii = ii+s%Nb
        call save_chain(s,w,ip,ii,ii+Lstag)
        call gen_staging(s,w,ip,ii,Lstag)
        s%S0(w) = 0.d0
     end do
     call evaluate(s)
-    call settle_half(s,half,active,accepted)
+    call settle_half(s,half,act,accepted)
   end subroutine mv_staging_half
 
   ! MoveHeadHalfChain / MoveTailHalfChain (reference vpi_mod.f90:1495-1817); the Delta S of
@@ -780,11 +827,17 @@ contains
     integer, intent(inout) :: accepted(s%W)
     integer :: w,Ls,ii,ie,ip
     real(8) :: wgt
+    logical :: act(s%W)
     call begin_stage(s)
+    act = active
     do w=1,s%W
        if (.not. active(w)) cycle
        s%aux_i(w) = int((Lmax-1)*mt_real(s%rng(w)))+2
-       s%want(w)  = s%aux_i(w)
+       if (s%aux_i(w)>s%Nb) then
+          act(w) = .false.                 ! longer than the half chain: drawn and rejected (see seg_outside)
+       else
+          s%want(w) = s%aux_i(w)
+       end if
     end do
     call plan_items(s)
     do w=1,s%W
@@ -792,6 +845,10 @@ contains
        ip = s%iworm(w)
        Ls = s%aux_i(w)
        call select_half(s,w,ip,half)
+       if (.not. act(w)) then
+          call draw_only(s,w,Ls*s%dim)
+          cycle
+       end if
        if (which==HEAD) then
           ii = 0
           if (half==2) ii = s%Nb
@@ -814,7 +871,7 @@ contains
        s%S0(w) = 0.d0
     end do
     call evaluate(s)
-    call settle_half(s,half,active,accepted)
+    call settle_half(s,half,act,accepted)
   end subroutine mv_end_staging_half
 
   ! kinetic weight of the broken link (reference vpi_mod.f90:1872-1873)
@@ -834,12 +891,20 @@ contains
     logical, intent(in)    :: active(s%W)
     integer, intent(inout) :: accepted(s%W)
     integer :: w,Ls,half,ii,ie,ip
+    logical :: act(s%W)
     call begin_stage(s)
+    act = active
     do w=1,s%W
        if (.not. active(w)) cycle
        s%aux_i(w) = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
        s%aux_k(w) = int(mt_real(s%rng(w))*2)+1
-       s%want(w)  = s%aux_i(w)
+       ! Lstag > Nb: the segment can reach below bead 0 / above bead 2Nb.  Drawn, never built, never accepted
+       ! (see seg_outside; the front end refuses Lstag > Nb when CWorm > 0, where the reference could accept it)
+       if (s%aux_i(w)>s%Nb) then
+          act(w) = .false.
+       else
+          s%want(w) = s%aux_i(w)
+       end if
     end do
     call plan_items(s)
     do w=1,s%W
@@ -847,6 +912,11 @@ contains
        ip   = ip_of(w)
        Ls   = s%aux_i(w)
        half = s%aux_k(w)
+       if (.not. act(w)) then
+          call draw_only(s,w,Ls*s%dim)
+          s%flag(w) = .false.
+          cycle
+       end if
        s%S0(w) = -log(s%CWorm*s%density)
        if (half==1) then
           ii = s%Nb-Ls; ie = s%Nb
@@ -863,7 +933,7 @@ contains
        call gen_staging(s,w,ip,ii,Ls)
     end do
     call evaluate(s)
-    call settle_simple(s,ip_of,active,accepted,-1)
+    call settle_simple(s,ip_of,act,accepted,-1)
     do w=1,s%W
        if (.not. active(w)) cycle
        ip = ip_of(w)
@@ -891,12 +961,18 @@ contains
     integer, intent(inout) :: accepted(s%W)
     integer :: w,Ls,half,ii,ie,ip,ic
     real(8) :: xold(s%dim),xnew(s%dim)
+    logical :: act(s%W)
     call begin_stage(s)
+    act = active
     do w=1,s%W
        if (.not. active(w)) cycle
        s%aux_i(w) = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
        s%aux_k(w) = int(mt_real(s%rng(w))*2)+1
-       s%want(w)  = s%aux_i(w)
+       if (s%aux_i(w)>s%Nb) then
+          act(w) = .false.                 ! reaches outside 0..2Nb: drawn and rejected (see seg_outside)
+       else
+          s%want(w) = s%aux_i(w)
+       end if
     end do
     call plan_items(s)
     do w=1,s%W
@@ -904,6 +980,10 @@ contains
        ip   = s%iworm(w)
        Ls   = s%aux_i(w)
        half = s%aux_k(w)
+       if (.not. act(w)) then
+          call draw_only(s,w,(Ls-1)*s%dim)
+          cycle
+       end if
        s%S0(w) = log(s%CWorm*s%density)
        if (half==1) then
           ii = s%Nb-Ls; ie = s%Nb;      ic = ie
@@ -920,7 +1000,7 @@ contains
        s%DK(w) = delta_k(s,link_r2(s,s%Path(:,ip,ii,w),s%Path(:,ip,ie,w)),Ls)
     end do
     call evaluate(s)
-    call settle_simple(s,s%iworm,active,accepted,+1)
+    call settle_simple(s,s%iworm,act,accepted,+1)
     do w=1,s%W
        if (.not. active(w)) cycle
        if (s%flag(w)) then
@@ -955,6 +1035,10 @@ contains
        Ls = 2*int(((Lmax-2)/2)*mt_real(s%rng(w)))+2
        ii = s%Nb-Ls
        ie = s%Nb
+       if (seg_outside(s,ii,ie)) then      ! the partner weights would be read below bead 0: no swap
+          uran = mt_real(s%rng(w))
+          cycle
+       end if
        ! partner selection with Gaussian weights around the worm tail
        Sw = 0.d0
        do ip=1,s%Np
@@ -991,6 +1075,8 @@ contains
        Ls = s%aux_i(w)
        ii = s%Nb-Ls
        ie = s%Nb
+       call need_beads(s,w,ik,ii,ie)
+       call need_beads(s,w,iw,ii,ie)
        s%Old(:,:,w)  = s%Path(:,ik,:,w)
        s%Old2(:,:,w) = s%Path(:,iw,:,w)
        s%seg_i(w) = ii; s%seg_e(w) = ie

@@ -91,9 +91,13 @@ program pigs_vpi
   NWtot = n_walkers
   G = max(1,min(n_gpus,NWtot))
   pi = acos(-1.d0)
-  if (device_sampler .and. Lstag>Nb .and. CWorm>0.d0) then
-     write (0,*) 'pigs_vpi: device_sampler = T with CWorm > 0 needs Lstag <= Nb (half-chain moves); using the host-driven sampler'
-     device_sampler = .false.
+  if (Lstag>Nb .and. CWorm>0.d0) then
+     ! the worm-sector movers cut segments of up to Lstag beads out of a HALF chain: beyond Nb the reference indexes
+     ! Path below bead 0 / above bead 2Nb (vpi_mod.f90:1853-1857, 2112-2116, 2300) and may even accept what it read
+     ! there.  With CWorm = 0 the open proposal is never accepted (quirk Q11) and both samplers only draw its
+     ! random numbers; with CWorm > 0 there is no defined result to reproduce: refuse the input.
+     write (0,*) 'pigs_vpi: CWorm > 0 needs Lstag <= Nb (worm moves act on half chains of Nb links)'
+     stop 2
   end if
 
   ! box, cutoff, grids (reference vpi.f90:82-128)

@@ -27,11 +27,11 @@ def exe(gpu_lib):
     return os.path.join(HOST, "pigs_vpi")
 
 
-def _run(exe, txt, wd):
+def _run(exe, txt, wd, env=None):
     with open(os.path.join(wd, "vpi.in"), "w") as f:
         f.write(txt)
     with open(os.path.join(wd, "vpi.in")) as fin, open(os.path.join(wd, "stdout.txt"), "w") as fo:
-        r = subprocess.run([exe], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=wd, timeout=900)
+        r = subprocess.run([exe], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=wd, timeout=900, env=env)
     assert r.returncode == 0, open(os.path.join(wd, "stdout.txt")).read()[-3000:]
 
 
@@ -236,6 +236,9 @@ def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     ("sta", "dim = 3, Np = 21, density = 0.2d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0"),
     # beyond the one-launch kernel's four levels: 2^5, 2^6 beads per bisection segment (pigs_diag.hip's stage machine)
     ("bis", "dim = 3, Np = 20, density = 0.3d0", "Nb = 40, Lstag = 30, Nlev = 6", "0.0d0"),
+    # Lstag > Nb at CWorm = 0: the never-accepted open proposal leaves the chain (both samplers draw it, build nothing)
+    ("bis", "dim = 3, Np = 20, density = 0.3d0", "Nb = 40, Lstag = 50, Nlev = 6", "0.0d0"),
+    ("sta", "dim = 3, Np = 21, density = 0.2d0", "Nb = 10, Lstag = 15, Nlev = 3", "0.0d0"),
     ("bis", "dim = 3, Np = 70, density = 0.3d0", "Nb = 20, Lstag = 8, Nlev = 5", "0.4d0"),
     # more OBDM iterations per step than round 1's fixed 64-int event log could hold (Nobdm <= 30)
     ("bis", "dim = 3, Np = 12, density = 0.3d0", "Nb = 10, Lstag = 6, Nlev = 2", "2.0d0, Nobdm = 45"),
@@ -309,16 +312,23 @@ def test_gpu_resume_from_reference_checkpoint(exe, dev, tmp_path):
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
 
 
+@pytest.mark.parametrize("dev,W", [("T", 1), ("F", 1), ("F", 3)])
 @pytest.mark.parametrize("name", ["lstag_gt_nb_bis6", "lstag_gt_nb_sta"])
-def test_gpu_device_sampler_lstag_beyond_nb(exe, name, tmp_path):
+def test_gpu_samplers_lstag_beyond_nb(exe, name, dev, W, tmp_path):
     """Lstag > Nb with CWorm = 0 (bisection with six levels / staging sampling): the reference's never-accepted open
-    proposal (quirk Q11) then reaches below bead 0 -- only its random numbers matter, and K6 consumes exactly those.
-    The host-driven sampler restates OpenChain literally and is not run here."""
+    proposal (quirk Q11) then reaches below bead 0 -- only its random numbers matter, and both samplers consume exactly
+    those and build nothing (host-driven: bit-identical worldline, also with three walkers, where round 2's
+    out-of-bounds stores corrupted the heap; glibc heap checking on)."""
     src = os.path.join(RUNS, name)
-    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = T\n/\n", str(tmp_path))
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + f"&gpu\n n_walkers = {W}, device = 0, device_sampler = {dev}\n/\n",
+         str(tmp_path), env=dict(os.environ, MALLOC_CHECK_="3"))
     assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
-    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape((W,) + want.shape)[0]
+    if dev == "F":
+        assert same_bits(got, want)
+    if W > 1:
+        return
     assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
     for f in ("e_vpi.out", "et_vpi.out"):
         assert _close(tmp_path / f, os.path.join(src, f)), f

@@ -1,9 +1,9 @@
 """Parity of the HIP path (through the C ABI, libpigs_hip.so) with the reference.
 
 Checkers, in order of authority: the committed golden vectors (generated from the unmodified
-reference), the pinned C restatement (oracle/) on fresh seeded inputs, the reference build
-itself where oracle/_ref travelled to this machine, and size-independent properties at the full
-BASELINE sizes.
+reference), the pinned C restatement (oracle/) on fresh seeded inputs, and size-independent
+properties at the full BASELINE sizes.  The compiled reference stays in the build container:
+nothing under -m gpu loads oracle/_ref (SURVEY.md 8c travel rule).
 
 Tolerances (fp64 path; stated per SURVEY §7 hard-part 2 and BASELINE.json's 1e-10):
   * per-pair terms are bit-identical to the reference's, only the summation order differs, so
@@ -259,37 +259,6 @@ def test_delta_action_vs_oracle_seeded(gpu_lib, oracle, Np, Nb, W, n):
         lo = oracle.local_energy(S, WF, VT, Paths[k][0])
         if np.all(np.isfinite(lo)):
             assert _close_rel([le[0][k], le[1][k], le[2][k]], lo)
-
-
-def test_against_reference_build_if_present(gpu_lib):
-    """Where oracle/_ref travelled to this machine, compare with the reference ITSELF."""
-    from oracle.pyoracle import Ref, System
-    from pathintegralgroundstate_amd import SystemConfig
-    if not Ref.available():
-        pytest.skip("oracle/_ref not present on this machine")
-    ref = Ref()
-    S = System(dim=3, Np=64, Nb=40)
-    cfg = SystemConfig(dim=3, Np=64, Nb=40)
-    VT, WF = ref.tables(S)
-    P, _ = ref.init(1982)
-    for ip in range(1, S.Np + 1):                     # a few reference moves so beads spread out
-        ref.translate_chain(0.3, WF, VT, ip, P)
-        ref.diag_move("Bisection", WF, VT, 4, ip, P)
-        ref.diag_move("MoveHeadBisection", WF, VT, 3, ip, P)
-        ref.diag_move("MoveTailBisection", WF, VT, 3, ip, P)
-    rng = np.random.default_rng(9)
-    w, ip, ib, xnew, xold = _random_batch(rng, S, P[None], 1500, 0.1)
-    want = np.array([ref.update_action(WF, VT, P, int(ip[i]), int(ib[i]), xnew[i], xold[i])
-                     for i in range(len(ip))])
-    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
-        ctx.upload(0, P)
-        got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
-        te = ctx.ThermEnergy(0)
-        le = ctx.LocalEnergy(0, 2 * S.Nb)
-    sv, sf, su = term_scales(S, VT, WF, P, ip, ib, xnew, xold)
-    assert np.all(np.abs(got - want) <= delta_s_tolerance(S, sv, sf, su))
-    assert _close_rel(te, ref.therm_energy(VT, P))
-    assert _close_rel(le, ref.local_energy(WF, VT, P[2 * S.Nb]))
 
 
 def test_commit_swap_and_edge_cases(gpu_lib, oracle):

@@ -82,6 +82,37 @@ def test_front_end_at_baseline_sizes(exe, name, tmp_path):
             assert open(os.path.join(src, f), "rb").read() == open(tmp_path / f, "rb").read(), f
 
 
+@pytest.mark.parametrize("W", [1, 3])
+@pytest.mark.parametrize("name", ["lstag_gt_nb_bis6", "lstag_gt_nb_sta"])
+def test_host_driven_sampler_lstag_beyond_nb(exe, name, W, tmp_path):
+    """Lstag > Nb at CWorm = 0 (input the reference runs: its never-accepted OpenChain proposal, quirk Q11, then
+    indexes Path below bead 0 / above bead 2Nb, vpi_mod.f90:1853-1857).  The host-driven sampler draws exactly that
+    proposal's random numbers and builds nothing (round 2 indexed its own arrays out of bounds there and corrupted
+    the heap from three walkers on).  Files byte-identical, final worldline bit-identical to the reference run;
+    glibc's heap checking on (MALLOC_CHECK_=3 aborts on the first corrupted chunk)."""
+    src = os.path.join(RUNS, name)
+    env = dict(os.environ, MALLOC_CHECK_="3", MALLOC_PERTURB_="165")
+    run_pigs_vpi(exe, open(os.path.join(src, "vpi.in")).read() +
+                 f"&gpu\n n_walkers = {W}, device = 0, device_sampler = F\n/\n", str(tmp_path), env=env)
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    assert same_bits(final_worldline(str(tmp_path), want.shape, W)[0], want)
+    for f in FILES:
+        mine = tmp_path / (f if W == 1 else f.replace(".out", ".w0000.out"))
+        assert open(os.path.join(src, f), "rb").read() == open(mine, "rb").read(), f
+
+
+def test_worm_sector_with_lstag_beyond_nb_is_refused(exe, tmp_path):
+    """CWorm > 0 with Lstag > Nb: the reference's half-chain movers would read and write outside Path and could accept
+    the result -- there is nothing defined to reproduce, so the front end stops with a message (both samplers)."""
+    txt = open(os.path.join(RUNS, "lstag_gt_nb_sta", "vpi.in")).read().replace("CWorm = 0.0d0", "CWorm = 0.5d0")
+    for dev in "FT":
+        with open(tmp_path / "vpi.in", "w") as f:
+            f.write(txt + f"&gpu\n n_walkers = 1, device = 0, device_sampler = {dev}\n/\n")
+        r = subprocess.run([exe], stdin=open(tmp_path / "vpi.in"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           cwd=tmp_path, timeout=120)
+        assert r.returncode == 2 and b"Lstag <= Nb" in r.stdout, r.stdout[-500:]
+
+
 def test_lockstep_walkers_reproduce_per_seed_reference_runs(exe, tmp_path):
     base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
     run_pigs_vpi(exe, base + "&gpu\n n_walkers = 3, device = 0\n/\n", str(tmp_path))
