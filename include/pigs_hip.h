@@ -95,6 +95,12 @@ int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */
 int pigs_selftest_fastmath(pigs_ctx *ctx, int32_t blocks, int32_t iters, uint64_t bad[4]);
+/* Device self-test: the log() inside the device-resident sampler's Box-Muller transform (csrc/pigs_log_host.h: glibc's
+ * algorithm and constants, the reference's `log` of random_mod.f90:213) against THIS host's libm, bit for bit, on n
+ * arguments of the sampler's domain (stream uniforms, polar radii, random mantissas, the near-one branch).
+ * *mismatches must come back 0 for the sampler's worldlines to be bit-identical to the reference's; *first_bad (may be
+ * NULL) = one differing argument. */
+int pigs_selftest_log(pigs_ctx *ctx, int64_t n, uint64_t seed, uint64_t *mismatches, double *first_bad);
 /* Measurement aid: `reps` plain streaming reads of the context's resident worldlines (the bytes a full-chain Delta-S
  * stage reads) by a kernel that does nothing else; *bytes per pass, *seconds per pass (HIP events on the context's
  * stream).  bench.py quotes it next to K1's roofline as the rate this chip's memory system delivers to a reader. */

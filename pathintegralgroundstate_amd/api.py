@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "pigs_commit_beads", "pigs_swap_tails", "pigs_potential_energy_slice",
     "pigs_therm_energy_batch", "pigs_local_energy_batch", "pigs_comm_unique_id",
     "pigs_comm_init_rank", "pigs_comm_init_all", "pigs_estimators_allreduce",
-    "pigs_set_tuning", "pigs_selftest_fastmath", "pigs_selftest_stream_read",
+    "pigs_set_tuning", "pigs_selftest_fastmath", "pigs_selftest_stream_read", "pigs_selftest_log",
     "pigs_stage_reserve", "pigs_delta_action_staged", "pigs_commit_reserve", "pigs_commit_staged",
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
     "pigs_sampler_counters", "pigs_sampler_counters16", "pigs_sampler_get_worm", "pigs_sampler_set_worm",
@@ -119,6 +119,7 @@ def load_library(path=LIB_PATH):
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     L.pigs_selftest_stream_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.pigs_selftest_log.argtypes = [vp, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name != "pigs_last_error":
@@ -249,6 +250,12 @@ class PigsContext:
         bad = (C.c_uint64 * 4)()
         _chk(self.L, self.L.pigs_selftest_fastmath(self.h, blocks, iters, bad), "pigs_selftest_fastmath")
         return list(bad), blocks * 256 * iters
+
+    def selftest_log(self, n=1 << 30, seed=0x5eed):
+        """(mismatches, one differing argument) of the sampler's device log against this host's libm on n arguments."""
+        bad, x = C.c_uint64(), C.c_double()
+        _chk(self.L, self.L.pigs_selftest_log(self.h, int(n), int(seed), C.byref(bad), C.byref(x)), "pigs_selftest_log")
+        return bad.value, x.value
 
     def stream_read(self, reps=50):
         """(bytes, seconds) per plain streaming read of the resident worldlines (measurement aid)."""

@@ -20,6 +20,8 @@
 #include <unordered_set>
 #include <atomic>
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 #include "pigs_comm.h"
 #include "pigs_kernels.h"
@@ -351,24 +353,73 @@ int pigs_selftest_fastmath(pigs_ctx *c, int32_t blocks, int32_t iters, uint64_t 
     return PIGS_OK;
 }
 
+// Device log of the sampler's Gaussians (pigs_log_host.h) against THIS host's libm, bit for bit, on n arguments of the
+// sampler's domain (selftest_log_arg): chunks of 2^24 results come back over PCIe and are compared by host threads
+// while the device computes the next chunk.
+int pigs_selftest_log(pigs_ctx *c, int64_t n, uint64_t seed, uint64_t *mismatches, double *first_bad)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!mismatches || n < 1) return fail(PIGS_ERR_ARG, "bad arguments");
+    const size_t chunk = (size_t)1 << 24;
+    double *d[2] = {nullptr, nullptr}, *h[2] = {nullptr, nullptr};
+    uint64_t bad = 0; double firstx = 0.0; bool have = false;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc((void **)&d[k], chunk * sizeof(double));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h[k], chunk * sizeof(double), hipHostMallocDefault);
+    }
+    auto compare = [&](const double *res, uint64_t first, size_t m) {
+        const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        std::vector<uint64_t> nb(nt, 0); std::vector<double> fx(nt, 0.0);
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (size_t i = t; i < m; i += nt) {
+                    const double x = selftest_log_arg(first + i, seed), want = std::log(x), got = res[i];
+                    if (memcmp(&want, &got, 8) != 0 && !(want != want && got != got)) { if (!nb[t]) fx[t] = x; ++nb[t]; }
+                }
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < nt; ++t) { if (nb[t] && !have) { firstx = fx[t]; have = true; } bad += nb[t]; }
+    };
+    uint64_t done = 0; int cur = 0; size_t prev_m = 0; uint64_t prev_first = 0;
+    while (e == hipSuccess && done < (uint64_t)n) {
+        const size_t m = (size_t)std::min<uint64_t>(chunk, (uint64_t)n - done);
+        e = launch_selftest_log(done, m, seed, d[cur], c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h[cur], d[cur], m * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (prev_m) compare(h[cur ^ 1], prev_first, prev_m);            // overlaps the chunk in flight
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        prev_m = m; prev_first = done; done += m; cur ^= 1;
+    }
+    if (e == hipSuccess && prev_m) compare(h[cur ^ 1], prev_first, prev_m);
+    for (int k = 0; k < 2; ++k) { if (d[k]) (void)hipFree(d[k]); if (h[k]) (void)hipHostFree(h[k]); }
+    if (e != hipSuccess) return fail(PIGS_ERR_HIP, "pigs_selftest_log: %s", hipGetErrorString(e));
+    *mismatches = bad;
+    if (first_bad) *first_bad = firstx;
+    return PIGS_OK;
+}
+
 int pigs_selftest_stream_read(pigs_ctx *c, int32_t reps, double *bytes, double *seconds)
 {
     int rc = check_ctx(c); if (rc) return rc;
     if (!bytes || !seconds || reps < 1) return fail(PIGS_ERR_ARG, "bad arguments");
     const size_t nd = c->path_doubles * (size_t)c->n_walkers;
     double *sink = nullptr;
-    HIPCHK(hipMalloc((void **)&sink, sizeof(double)));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    for (int r = 0; r < 3; ++r) HIPCHK(launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream));
-    HIPCHK(hipEventRecord(e0, c->stream));
-    for (int r = 0; r < reps; ++r) HIPCHK(launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream));
-    HIPCHK(hipEventRecord(e1, c->stream));
-    HIPCHK(hipEventSynchronize(e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    HIPCHK(hipFree(sink));
+    hipError_t e = hipMalloc((void **)&sink, sizeof(double));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    for (int r = 0; r < 3 && e == hipSuccess; ++r) e = launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_stream_read(c->d_paths, nd, c->n_cu, sink, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);                    // nothing leaks on an error return
+    if (e1) (void)hipEventDestroy(e1);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(PIGS_ERR_HIP, "pigs_selftest_stream_read: %s", hipGetErrorString(e));
     *bytes = (double)(nd * sizeof(double));
     *seconds = 1e-3 * (double)ms / reps;
     return PIGS_OK;

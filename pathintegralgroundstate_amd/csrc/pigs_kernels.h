@@ -86,6 +86,23 @@ hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned 
 int sweep_form(const DevParams &P, const SweepParams &sp, int threads);   // workgroup size launch_sweep uses for a request
 
 hipError_t launch_stream_read(const double *a, size_t doubles, int blocks, double *sink, hipStream_t st);
+// argument `idx` of the log self-test (pigs_selftest_log): the device sampler's domain -- a uniform of the stream
+// k/(2^32-1); a polar radius u1^2+u2^2 <= 1 of two such uniforms; a random mantissa over 2^-69 .. 2; the near-one branch
+__host__ __device__ inline double selftest_log_arg(unsigned long long idx, unsigned long long seed)
+{
+    unsigned long long z = (idx + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    unsigned long long y = (z + 0x632BE59BD9B4E019ull) * 0xD1342543DE82EF95ull; y ^= y >> 29;
+    const double ua = (double)(unsigned int)z / 4294967295.0, ub = (double)(unsigned int)y / 4294967295.0;
+    switch (idx & 3) {
+    case 0: return ua;
+    case 1: { const double u1 = 2.0 * ua - 1.0, u2 = 2.0 * ub - 1.0; const double q = u1 * u1 + u2 * u2; return q > 1.0 ? q - 1.0 : q; }
+    case 2: { const unsigned long long ix = (z >> 12) | ((unsigned long long)(0x3ff - (y % 70)) << 52);
+              double x; __builtin_memcpy(&x, &ix, 8); return x; }
+    default: return 0.9375 + (double)(z >> 11) * (1.0 / 9007199254740992.0) * 0.13;
+    }
+}
+hipError_t launch_selftest_log(unsigned long long first, unsigned long long n, unsigned long long seed, double *d_out, hipStream_t st);
 hipError_t launch_selftest_fastmath(const DevParams &P, unsigned long long seed, int blocks, int iters,
                                     unsigned long long *d_bad, hipStream_t st);
 

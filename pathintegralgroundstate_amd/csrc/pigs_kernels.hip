@@ -12,6 +12,7 @@
 #include "pigs_device.h"
 #include "pigs_k1_device.h"
 #include "pigs_kernels.h"
+#include "pigs_log_host.h"
 
 namespace pigs {
 
@@ -610,6 +611,19 @@ __global__ __launch_bounds__(1024) void k_stream_read(const double2 *__restrict_
     }
     for (; i < n; i += stride) { const double2 x = a[i]; s += x.x + x.y; }
     if (s == 1.2345e-300) sink[0] = s;                                // (never: keeps the loads)
+}
+
+// out[i] = log_host(argument first+i): the device routine the sampler's Gaussians use, checked on the host against libm
+__global__ void k_selftest_log(unsigned long long first, unsigned long long n, unsigned long long seed, double *out)
+{
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log_host(selftest_log_arg(first + i, seed));
+}
+
+hipError_t launch_selftest_log(unsigned long long first, unsigned long long n, unsigned long long seed, double *d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_log, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, first, n, seed, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_stream_read(const double *a, size_t doubles, int blocks, double *sink, hipStream_t st)

@@ -5,6 +5,7 @@
 
 #include "pigs_device.h"
 #include "pigs_kernels.h"
+#include "pigs_log_host.h"
 
 namespace pigs {
 
@@ -83,9 +84,10 @@ __device__ __forceinline__ void rng_produce(const Rng &R, int want, int lane)
         const double u2 = 2.0 * mt_real(R.W[ring_w(k + 1)]) - 1.0;
         const double q  = u1 * u1 + u2 * u2;
         double g = __builtin_nan("");
-        if (q <= 1.0) g = u1 * sqrt_exact((-2.0 * log(q)) / q);
+        // log_host: the host libm's log to the bit (pigs_log_host.h) -- the Gaussians are the reference's, bit for bit
+        if (q <= 1.0) g = u1 * sqrt_exact((-2.0 * log_host(q)) / q);
         R.Gc[k % kGRing] = g;
-        R.Lc[k % kGRing] = log(uk);
+        R.Lc[k % kGRing] = log_host(uk);
     }
     gd = gd + kWave < gmax ? gd + kWave : (gd > gmax ? gd : gmax);
     __builtin_amdgcn_wave_barrier();

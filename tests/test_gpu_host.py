@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
-from helpers import (MIXED_TOL_NOT_BIT_IDENTICAL, block_energy_errors, check_worldline_vs_driver, driver_blocks,
+from helpers import (MIXED_TOL, block_energy_errors, check_worldline_vs_driver, driver_blocks,
                      fold_maxnorm, read_hex_blocks, same_bits)
 from pathintegralgroundstate_amd import SystemConfig
 
@@ -48,7 +48,7 @@ def _hex_close(hexfile, src, rel=1e-10, mixed=1e-10):
     """Block energies E K V Et Kt Vt (per particle) of e_vpi*.hex against the 64-bit values of the reference's own
     estimators run in the program's schedule (driver.npz): 1e-10 relative (helpers.block_energy_errors), no printing
     floor.  `mixed` is the bound for the E, K columns: 1e-10 where the worldline is bit-identical (host-driven
-    sampler), helpers.MIXED_TOL_NOT_BIT_IDENTICAL for the device-resident sampler (see there)."""
+    sampler), helpers.MIXED_TOL for the device-resident sampler (see there)."""
     drv = dict(np.load(os.path.join(src, "driver.npz")))
     blocks, rows = read_hex_blocks(hexfile)
     wb, wrows = driver_blocks(drv)
@@ -124,8 +124,8 @@ def test_gpu_front_end_device_sampler_at_baseline_sizes(exe, name, tmp_path):
     shape = tuple(int(x) for x in drv["Path_shape"])
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(shape)
     Lbox, trap = _lbox(src)
-    check_worldline_vs_driver(got, drv, Lbox, trap, tol=1e-10)
-    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
+    check_worldline_vs_driver(got, drv, Lbox, trap, tol=0.0)           # bit-identical: SHA-256 of every coordinate
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL)
     if os.path.exists(os.path.join(src, "nr_vpi.out")):
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     if os.path.exists(os.path.join(src, "gr_vpi.out")):
@@ -154,9 +154,8 @@ def test_gpu_front_end_with_device_resident_sampler(exe, tmp_path):
     for w, seed in enumerate((1982, 1983)):
         src = os.path.join(RUNS, f"he4_bis_cworm0_s{seed}")
         want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
-        d = got.reshape((2,) + want.shape)[w] - want
-        assert fold_maxnorm(d, *_lbox(src)) < 1e-10
-        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
+        assert same_bits(got.reshape((2,) + want.shape)[w], want), w
+        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL)
         assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
         assert _close(tmp_path / f"sk_vpi.w{w:04d}.out", os.path.join(src, "sk_vpi.out"), rel=1e-8)
 
@@ -171,9 +170,8 @@ def test_gpu_front_end_device_sampler_worm_sector(exe, tmp_path):
     for w, seed in enumerate((1982, 1983, 1984)):
         src = os.path.join(RUNS, f"he4_worm_s{seed}")
         want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
-        d = got.reshape((3,) + want.shape)[w] - want
-        assert fold_maxnorm(d, *_lbox(src)) < 1e-10, w
-        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
+        assert same_bits(got.reshape((3,) + want.shape)[w], want), w
+        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src, mixed=MIXED_TOL)
         assert _close(tmp_path / f"gr_vpi.w{w:04d}.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / f"nr_vpi.w{w:04d}.out", "rb").read(), w
         assert open(tmp_path / f"perm_vpi.w{w:04d}.out").read().split() == open(os.path.join(src, "fort.99")).read().split(), w
@@ -189,8 +187,8 @@ def test_gpu_front_end_device_sampler_stock_input(exe, tmp_path):
     assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
-    assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
-    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
+    assert same_bits(got, want)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL)
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
 
@@ -205,8 +203,8 @@ def test_gpu_front_end_device_sampler_staging_movers(exe, name, tmp_path):
     assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
-    assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
-    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL_NOT_BIT_IDENTICAL)
+    assert same_bits(got, want)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL)
     if os.path.exists(os.path.join(src, "nr_vpi.out")):
         assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
@@ -280,12 +278,12 @@ def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, 
     wa, wb = np.fromfile(a / "worldlines_final.bin"), np.fromfile(b / "worldlines_final.bin")
     cfg = SystemConfig.from_namelists(inp)
     assert wa.shape == wb.shape
-    assert fold_maxnorm((wa - wb).reshape(-1, cfg.dim), cfg.Lbox, False) < 1e-10
+    assert same_bits(wa, wb), "device-resident and host-driven sampler: worldlines differ"
     for w in range(3):
         ba, ra = read_hex_blocks(a / f"e_vpi.w{w:04d}.hex")
         bb, rb = read_hex_blocks(b / f"e_vpi.w{w:04d}.hex")
         em, er = block_energy_errors(rb, ra)
-        assert np.array_equal(ba, bb) and np.all(er <= 1e-10) and np.all(em <= MIXED_TOL_NOT_BIT_IDENTICAL), w
+        assert np.array_equal(ba, bb) and np.all(er <= 1e-10) and np.all(em <= MIXED_TOL), w
         assert open(a / f"nr_vpi.w{w:04d}.out", "rb").read() == open(b / f"nr_vpi.w{w:04d}.out", "rb").read(), w
         assert open(a / f"perm_vpi.w{w:04d}.out").read() == open(b / f"perm_vpi.w{w:04d}.out").read(), w
 
@@ -303,10 +301,7 @@ def test_gpu_resume_from_reference_checkpoint(exe, dev, tmp_path):
          str(tmp_path))
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
-    if dev == "F":
-        assert same_bits(got, want)
-    else:
-        assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
+    assert same_bits(got, want)
     for f in ("e_vpi.out", "et_vpi.out"):
         assert _close(tmp_path / f, os.path.join(src, f)), f
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
@@ -325,11 +320,9 @@ def test_gpu_samplers_lstag_beyond_nb(exe, name, dev, W, tmp_path):
     assert "using the host-driven sampler" not in open(tmp_path / "stdout.txt").read()
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape((W,) + want.shape)[0]
-    if dev == "F":
-        assert same_bits(got, want)
+    assert same_bits(got, want)
     if W > 1:
         return
-    assert fold_maxnorm(got - want, *_lbox(src)) < 1e-10
     for f in ("e_vpi.out", "et_vpi.out"):
         assert _close(tmp_path / f, os.path.join(src, f)), f
     assert _close(tmp_path / "gr_vpi.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)

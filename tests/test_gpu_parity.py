@@ -701,3 +701,16 @@ def test_commit_list_is_a_sequence_last_value_wins(gpu_lib):
     for i in range(n):
         want[w[i], ib[i], ip[i] - 1] = x[i]
     assert same_bits(got, want)
+
+
+def test_device_log_is_the_host_libm_log_bit_for_bit(gpu_lib):
+    """pigs_selftest_log: the log() inside the device sampler's Box-Muller transform (csrc/pigs_log_host.h, glibc's
+    algorithm + constants with the x86-64 FMA build's fusions) against THIS host's libm on 2^30 arguments of the
+    sampler's domain (stream uniforms, polar radii, random mantissas, the near-one branch): zero mismatches, which is
+    what makes the device-resident sampler's worldlines bit-identical to the reference's."""
+    from pathintegralgroundstate_amd import SystemConfig
+    cfg = SystemConfig(dim=3, Np=8, Nb=2)
+    VT, WF = gpu_lib.build_tables(cfg)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
+        bad, x = ctx.selftest_log(1 << 30, seed=20261004)
+    assert bad == 0, (bad, float(x).hex())

@@ -155,3 +155,20 @@ def test_lj_and_dipolar_table_fill():
         # (1/r^6 - 1) cancels at r = 1: compare on the scale of the two terms, not in ulps of the difference
         assert np.all(np.abs(VT[fin] - want[fin]) <= 1e-14 * (np.abs(want[fin]) + 22.0228))
         assert VT[0] == VT[2] and VT[c.Nmax + 1] == VT[c.Nmax]
+
+
+def test_log_host_matches_this_machines_libm(tmp_path):
+    """csrc/pigs_log_host.h (the device sampler's log) compiled for the CPU with the same fusions (g++ -mfma,
+    -ffp-contract=off) against libm's log on 2e8 arguments of the sampler's domain: identical bits.  On the GPU the
+    same source is checked by pigs_selftest_log (tests/test_gpu_parity.py)."""
+    import subprocess
+    from conftest import ROOT
+    if "fma" not in open("/proc/cpuinfo").read():
+        pytest.skip("this CPU has no FMA: glibc resolves log to another build")
+    exe = str(tmp_path / "log_host_check")
+    subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp",
+                           "-I" + os.path.join(ROOT, "pathintegralgroundstate_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "shim", "log_host_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=600)
+    tested, bad, first = out.stdout.split()
+    assert out.returncode == 0 and int(bad) == 0 and int(tested) >= 200000000, out.stdout
