@@ -46,7 +46,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 vector peak (SURVEY 8d
 # sqrt (8), V interpolation (8) on every slice; dV/dr interpolation (10), 1/r (4), force terms on both particles (9) on
 # odd slices -> 33 / 56, 44.5 on average over a chain
 K2_FLOPS_PER_PAIR = 44.5
-TRAFFIC_FILE = os.path.join("profiles", "r02_k1_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_k1_hbm_traffic.json")
 
 
 # K1 kernel behind each k1_variant on the bench workload (0 = the library's choice: periodic system, Np <= 256,
@@ -122,6 +122,50 @@ def cpu_baseline(cfg, VT, WF, Paths, sets, budget_s=12.0):
                 all_cores=dict(value=allc, cores=nthr)), out
 
 
+def cpu_sweep_baseline(np_, nb):
+    """Same-box CPU figure for the MC-sweeps half of the metric: the build's own CPU restatement of one walker's sweep
+    -- the Fortran host sampler (host/pigs_sampler.f90, bit-identical to the reference's movers) over the C-ABI served by
+    the scalar CPU oracle (tests/shim: test infrastructure, used here only as the thing TIMED for the baseline) -- run as
+    the front end runs it: N=256, 161 beads, stock schedule, estimators every step, 1 core.  Two runs (2 and 14 MC steps)
+    so that set-up (tables, init, files) cancels: sweeps/s = 12 / (t14 - t2)  (~10 s of CPU work)."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from hostlib import BUILD, build_cpu_host
+        exe = os.path.join(BUILD, "pigs_vpi")
+        if not os.path.exists(exe):
+            exe = build_cpu_host()[2]
+    finally:
+        sys.path.pop(0)
+    inp = ("&system\n dim = 3, Np = %d, density = 0.365d0, trap = F\n/\n&samp\n resume = F, dt = 5.0d-3, Nb = %d, seed = 1982, "
+           "delta_cm = 0.12d0, CMFreq = 1,\n sampling = 'bis', Lstag = %d, Nlev = 4, Nstag = 5,\n Nblock = 1, Nstep = %%d, Nbin = 100, "
+           "Nk = 50\n/\n&obdm\n swapping = T, CWorm = 0.0d0, Nobdm = 0, Npw = 0\n/\n&wavefun\n Nmax = 10000, wf_table = T, "
+           "v_table = T\n/\n&jastrow\n Rm = 1.20d0\n/\n&extpot\n a_ho = 1.0d0\n/\n&gpu\n n_walkers = 1, device = 0, "
+           "device_sampler = F, checkpointing = F\n/\n" % (np_, nb, min(32, nb)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", PIGS_HOST_THREADS="1")
+    times = {}
+    for nstep in (2, 14):
+        with tempfile.TemporaryDirectory() as td:
+            with open(os.path.join(td, "vpi.in"), "w") as f:
+                f.write(inp % nstep)
+            t0 = time.perf_counter()
+            with open(os.path.join(td, "vpi.in")) as fin, open(os.path.join(td, "out.txt"), "w") as fo:
+                subprocess.run([exe], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=td, check=True, timeout=600, env=env)
+            times[nstep] = time.perf_counter() - t0
+    per_sweep = (times[14] - times[2]) / 12.0
+    return dict(value=1.0 / per_sweep, unit="walker-sweeps/s", cores=1, kind="port",
+                sample="12 MC steps of one N=%d, %d-bead walker (stock schedule + estimators): Fortran host sampler over the "
+                       "scalar C oracle; %.2f s for 14 steps - %.2f s for 2 steps" % (np_, 2 * nb + 1, times[14], times[2]))
+
+
+def launch_stats(ms):
+    """median / min / max / mean of per-launch durations (ms)."""
+    a = np.asarray(ms, float)
+    return {"median_ms": float(np.median(a)), "min_ms": float(a.min()), "max_ms": float(a.max()), "mean_ms": float(a.mean()),
+            "p10_ms": float(np.percentile(a, 10)), "p90_ms": float(np.percentile(a, 90)), "launches": int(a.size)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +180,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse "
                                                       "the multi-process path on a one-GPU machine)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--mc-steps", type=int, default=14, help="MC steps per timed leg of the device-resident sampler (>= 0.5 s at 128 walkers)")
+    ap.add_argument("--mc-large-walkers", type=int, default=1024, help="walkers of the second sampler leg (0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -208,6 +254,17 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # per-launch durations (a pass of its own after the timed region: one event between every two launches)
+    def per_launch(fn, n, stream):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record(stream)
+        for i in range(n):
+            fn(i)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        return [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+    k1_launches = launch_stats(per_launch(step, min(200, max(20, args.steps)), kstream))
+
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -258,7 +315,10 @@ def main():
             w, ip, ib, xn, xo = dL[i % 2]
             ctxL.delta_action_batch_dev(nL, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(),
                                         oL.data_ptr())
-        for i in range(6):
+        # warm-up: the context was just created and filled (seconds of host work with an idle GPU): first touch of the
+        # 380 MB, TLB fill and the clock ramp all sit in the first launches -- round 2 timed 6 launches after creation and
+        # saw 72-121 us for the same launch.  40 launches (~4 ms) before anything is timed.
+        for i in range(40):
             stepL(i)
         ctxL.sync()
         nstepL = max(10, min(args.steps, 100))
@@ -270,6 +330,7 @@ def main():
         ctxL.sync()
         torch.cuda.synchronize()
         msL = e0.elapsed_time(e1) / nstepL
+        large_launches = launch_stats(per_launch(stepL, 100, ksL))
         bytesL = nL * (cfg.dim * cfg.Np * 8 + 2 * cfg.dim * 8 + 8)
         trafficL = None
         try:
@@ -282,7 +343,7 @@ def main():
                  "traffic_source": (TRAFFIC_FILE + " (same PMC passes)") if trafficL is not None else None, "working_set_bytes": int(WL * cfg.M * cfg.dim * cfg.Np * 8),
                  "algorithmic_bytes_per_launch": bytesL, "kernel_ms": msL, "achieved": bytesL / (msL * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytesL / (msL * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "steps": nstepL, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
+                 "steps": nstepL, "per_launch": large_launches, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
                                           "than the 256 MiB Infinity Cache, so every slice comes from HBM"}
         try:
             sb, st_s = ctxL.stream_read(30)
@@ -305,43 +366,64 @@ def main():
         for w in range(W):
             ctx.sampler_seed(w, 1982 + rank * W + w)
         acc0 = ctx.sampler_counters()
+        # warm-up: two whole MC steps from the jittered-lattice start (kernel attributes, first touch, the first sweep's
+        # many rejections), untimed
         ctx.sampler_step(1)
+        ctx.sampler_step(2)
         ctx.sync()
-        nmc = 3
+        nmc = max(1, args.mc_steps)
+        istep = 2
+
+        def timed_steps(fn):
+            """nmc calls of fn, each followed by a stream synchronisation: per-step wall times (s) and their sum.  The
+            synchronisation costs ~10 us of a ~40 ms step and makes min / median / max of a step visible."""
+            ts = []
+            for _ in range(nmc):
+                t = time.perf_counter()
+                fn()
+                ctx.sync()
+                ts.append(time.perf_counter() - t)
+            return ts
         if world > 1:
             dist.barrier()
+
+        def moves_only():
+            nonlocal istep
+            istep += 1
+            ctx.sampler_step(istep)
         t1 = time.perf_counter()
-        for i in range(nmc):
-            ctx.sampler_step(2 + i)
-        ctx.sync()
+        ts_moves = timed_steps(moves_only)
         mc_el = time.perf_counter() - t1
         if world > 1:
             tt = torch.tensor([mc_el], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             mc_el = float(tt.item())
-        acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 1))
+        acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 2))
         # the same steps followed by the diagonal-sector estimators of vpi.f90:443-469 (2 x LocalEnergy K4,
-        # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker: SURVEY 8d's definition of a sweep.  The block's
-        # estimator vector (what the front end accumulates per block: vpi.f90:456-469) is filled from them and
-        # all-reduced ONCE at the end of the block, inside the timed region.
+        # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker -- ONE library call and one synchronisation per step
+        # (pigs_diagonal_estimators): SURVEY 8d's definition of a sweep.  The block's estimator vector (what the front end
+        # accumulates per block: vpi.f90:456-469) is filled from them and all-reduced ONCE at the end of the block,
+        # inside the timed region.
         from pathintegralgroundstate_amd.sharding import EstimatorVector
         ev = EstimatorVector(Nbin=100, Nk=50, dim=3, Npw=0)
         c16_0 = ctx.sampler_counters16()
         if world > 1:
             dist.barrier()
-        t2 = time.perf_counter()
-        for i in range(nmc):
-            ctx.sampler_step(2 + nmc + i)
-            E1, _, _ = ctx.local_energy_batch(0)
-            E2, _, _ = ctx.local_energy_batch(2 * cfg.Nb)
-            Et, Kt, Pt = ctx.therm_energy_batch()
-            gr, Sk = ctx.structure_batch(cfg.Nb, 100, cfg.rcut / 100.0, 50)
-            E = 0.5 * (E1 + E2)
+
+        def full_step():
+            nonlocal istep
+            istep += 1
+            ctx.sampler_step(istep)
+            r = ctx.diagonal_estimators(100, cfg.rcut / 100.0, 50)
+            E = 0.5 * (r["E1"] + r["E2"])
+            Pt = r["Vt"]
             K = E - Pt
             ev.add("n_diag", W)
-            for name, v in (("E", E), ("K", K), ("V", Pt), ("Et", Et), ("Kt", Kt), ("Vt", Pt)):
+            for name, v in (("E", E), ("K", K), ("V", Pt), ("Et", r["Et"]), ("Kt", r["Kt"]), ("Vt", Pt)):
                 ev.add(name, v.sum()); ev.add(name + "2", (v * v).sum())
-            ev.add("gr", gr.sum(0)); ev.add("Sk", Sk.sum(0).T.ravel()); ev.add("ngr", W)
+            ev.add("gr", r["gr"].sum(0)); ev.add("Sk", r["Sk"].sum(0).T.ravel()); ev.add("ngr", W)
+        t2 = time.perf_counter()
+        ts_full = timed_steps(full_step)
         c16 = (ctx.sampler_counters16() - c16_0).sum(0)
         for name, q in (("acc_cm", 0), ("acc_head", 1), ("acc_tail", 2), ("acc_bd", 3), ("try_open", 4), ("try_cm", 14),
                         ("try_stag", 15)):
@@ -355,6 +437,7 @@ def main():
             reduced = mine.copy()
         ctx.sync()
         mc_full = time.perf_counter() - t2
+        reduce_ok = None
         if world > 1:
             tt = torch.tensor([mc_full], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -363,12 +446,42 @@ def main():
             parts_ = [torch.zeros(ev.size, dtype=torch.float64, device=red_dev) for _ in range(world)]
             dist.all_gather(parts_, torch.from_numpy(mine).to(red_dev))
             want_sum = np.sum([q.cpu().numpy() for q in parts_], axis=0)
-            assert np.allclose(reduced, want_sum, rtol=1e-12, atol=0), "estimator all-reduce disagrees with the sum of the ranks"
-        assert reduced[ev.fields["n_diag"]][0] == world * W * nmc
-        est_summary = {"length": int(ev.size), "n_diag": float(reduced[ev.fields["n_diag"]][0]),
+            reduce_ok = bool(np.allclose(reduced, want_sum, rtol=1e-12, atol=0))
+            assert reduce_ok, "estimator all-reduce disagrees with the sum of the ranks"
+        n_diag_got, n_diag_want = float(reduced[ev.fields["n_diag"]][0]), float(world * W * nmc)
+        assert n_diag_got == n_diag_want, (n_diag_got, n_diag_want)
+        est_summary = {"length": int(ev.size), "n_diag": n_diag_got,
+                       # proof that every rank's shard went through the reduction: n_diag == ranks x walkers/rank x steps
+                       "n_diag_expected": n_diag_want, "n_diag_check": n_diag_got == n_diag_want,
+                       "ranks_reduced": world, "global_walkers": world * W, "sum_equals_sum_of_ranks": reduce_ok,
                        "E_per_particle": float(reduced[ev.fields["E"]][0] / reduced[ev.fields["n_diag"]][0] / cfg.Np),
                        "Et_per_particle": float(reduced[ev.fields["Et"]][0] / reduced[ev.fields["n_diag"]][0] / cfg.Np),
                        "collective": "all_reduce(sum, f64) x1 per block" if world > 1 else "none (one rank)"}
+        # the sampler alone on the second walker count (1 024 walkers = 4 per CU): moves only
+        mc_large = None
+        if args.mc_large_walkers > 0 and world == 1:
+            WL2 = args.mc_large_walkers
+            ctx2 = api.PigsContext(cfg, VT, WF, n_walkers=WL2, device_id=local)
+            try:
+                P2, _ = make_workload(cfg, min(WL2, 64), 1, seed=777)
+                ctx2.upload_all(np.concatenate([P2] * ((WL2 + len(P2) - 1) // len(P2)))[:WL2])
+                del P2
+                ctx2.sampler_init(Nlev=mcfg.Nlev, Nstag=mcfg.Nstag, CMFreq=1, Lstag=min(32, args.nb), delta_cm=mcfg.delta_cm_eff)
+                for w in range(WL2):
+                    ctx2.sampler_seed(w, 5000 + w)
+                ctx2.sampler_step(1)
+                ctx2.sync()
+                n2 = max(2, min(5, nmc))
+                ts2 = []
+                for q in range(n2):
+                    t = time.perf_counter()
+                    ctx2.sampler_step(2 + q)
+                    ctx2.sync()
+                    ts2.append(time.perf_counter() - t)
+                mc_large = {"walkers": WL2, "walker_sweeps_per_s": WL2 * n2 / sum(ts2), "ms_per_mc_step": 1e3 * sum(ts2) / n2,
+                            "per_step": launch_stats([1e3 * t for t in ts2]), "note": "moves only; four walkers per CU"}
+            finally:
+                ctx2.close()
         # K2 alone (ThermEnergy of every walker: 2Nb slices x Np(Np-1)/2 pairs each) against the FP64 vector peak
         ctx.therm_energy_batch()
         t3 = time.perf_counter()
@@ -383,15 +496,19 @@ def main():
         # Delta-S items of one sweep of one walker: Np*(2Nb+1) + the bisection stages actually run;
         # the exact count depends on early exits, so it is bounded by SURVEY 8d's schedule
         mc = {"walker_sweeps_per_s": world * W * nmc / mc_full, "ms_per_mc_step": 1e3 * mc_full / nmc,
-              "moves_only": {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc},
-              "walkers_per_gpu": W,
+              "mc_steps_timed": nmc, "per_step": launch_stats([1e3 * t for t in ts_full]),
+              "moves_only": {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc,
+                             "per_step": launch_stats([1e3 * t for t in ts_moves])},
+              "walkers_per_gpu": W, "moves_only_large": mc_large,
               "kernels": "pigs::k_sweep (open/close attempt; bisection + worm moves) around pigs::k_cm (TranslateChain on 2 CUs per "
                          "walker while CUs >= 2 x walkers) + k_local_energy x2, k_slice_energy, "
                          "k_therm_combine, k_structure per step",
               "accepted_moves_per_sweep_per_walker": {"cm": acc[0], "head": acc[1], "tail": acc[2], "bisection": acc[3]},
               "schedule": "CMFreq=1 Nstag=5 Nlev=4 sampling=bis CWorm=0 (stock vpi.in), estimators every step",
               "estimator_vector": est_summary,
-              "reference_cpu_sweeps_per_s_per_core": 1.24}
+              # measured in the survey container, NOT on this box: the same-box figure is `cpu_baseline` below
+              "reference_program_sweeps_per_s_per_core_survey_container": 1.24,
+              "cpu_baseline": None}
         # the sampler's bead-pair rate (16.36 M bead-pair Delta-S evaluations per sweep of one walker at this
         # size and schedule, measured on the reference) against K1's kernel-only rate on the same GPU
         mc_pairs = 16.36e6 * W * nmc / mc_el
@@ -418,16 +535,22 @@ def main():
             want = Oracle().delta_action_batch(S, WF, VT, Paths, w[sel], ip[sel], ib[sel], xnew[sel], xold[sel])
             err = np.abs(got[sel] - want) / (np.abs(want) + 1e-9 * np.max(np.abs(want)))
             assert np.all(err < 1e-8), "bench output disagrees with the oracle: %g" % err.max()
+            if isinstance(mc, dict) and "error" not in mc:
+                try:
+                    mc["cpu_baseline"] = cpu_sweep_baseline(cfg.Np, cfg.Nb)
+                except Exception as e:                           # noqa: BLE001 -- the baseline is reported, never required
+                    mc["cpu_baseline"] = {"error": repr(e)[:300]}
         result = {
             "metric": "bead-pair action evals/sec (K1 Delta-S, N=256 Nb=161 4He, 128 walkers/GPU)",
             "value": value, "unit": "bead-pair action evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "liquid 4He N=%d beads=%d (namelist Nb=%d), %d walkers/GPU, one full-chain "
-                                   "Delta-S stage per step (%d items x %d partners)"
-                                   % (cfg.Np, cfg.M, cfg.Nb, W, n_items, cfg.Np - 1),
-                       "walkers_per_gpu": W, "items_per_step": n_items,
+            "config": {"workload": "liquid 4He N=%d beads=%d (namelist Nb=%d), %d walkers/GPU x %d GPU(s) = %d walkers, one "
+                                   "full-chain Delta-S stage per step (%d items x %d partners per GPU)"
+                                   % (cfg.Np, cfg.M, cfg.Nb, W, world, W * world, n_items, cfg.Np - 1),
+                       "walkers_per_gpu": W, "global_walkers": W * world, "items_per_step": n_items,
+                       "items_per_step_global": n_items * world,
                        "stages_per_sweep_equiv": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -437,8 +560,8 @@ def main():
                                            if traffic is not None else None,
                          "kernel": K1_KERNELS.get(args.variant, "pigs::k_delta_action_v2<...> (variant %d)" % args.variant),
                          "kernel_source": "library dispatch rule (pigs_k1.hip launch_delta_action); confirmed by "
-                                          "profiles/r02_bench_kernel_stats.csv",
-                         "kernel_ms": kern_ms,
+                                          "profiles/r03_bench_kernel_stats.csv",
+                         "kernel_ms": kern_ms, "per_launch": k1_launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "streaming_read_same_bytes": stream_read},
             "roofline_large": large,

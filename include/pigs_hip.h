@@ -234,6 +234,14 @@ int pigs_local_energy_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, in
  * The caller accumulates and normalises as the reference does.  PBC only. */
 int pigs_structure_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t ib, int32_t Nbin,
                          double rbin, int32_t Nk, double *gr, double *Sk);
+/* Every diagonal-sector estimator of one MC step (what vpi.f90:443-469 evaluates after a diagonal step) for n walkers in
+ * ONE call: LocalEnergy at slices 0 and 2Nb (sample_mod.f90:154-319), ThermEnergy (sample_mod.f90:323-388), and -- when
+ * gr and Sk are given (PBC runs) -- g(r) and S(k) at slice Nb (sample_mod.f90:392-473).  walkers may be NULL (0..n-1).
+ * en[9*i + 0..2] = E, Kin, Pot at slice 0; [3..5] the same at slice 2Nb; [6..8] = E, Ec, Ep of ThermEnergy.
+ * gr: n x Nbin, Sk: n x Nk x dim, laid out as pigs_structure_batch does.  Same results as the separate entry points
+ * (the same kernels), one synchronisation instead of four. */
+int pigs_diagonal_estimators(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t Nbin, double rbin, int32_t Nk,
+                             double *en, double *gr, double *Sk);
 
 /* ---- multi-GPU: block-estimator reduction (new) ------------------------ */
 /* RCCL communicator over `nranks` contexts.  Single-process form (one host thread per

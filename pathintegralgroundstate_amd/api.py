@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
     "pigs_sampler_counters", "pigs_sampler_counters16", "pigs_sampler_get_worm", "pigs_sampler_set_worm",
     "pigs_sampler_events", "pigs_sampler_event_ints", "pigs_sampler_nrho", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
+    "pigs_diagonal_estimators",
 ]
 
 
@@ -116,6 +117,7 @@ def load_library(path=LIB_PATH):
     L.pigs_sampler_nrho.argtypes = [vp, _dp, _ip]
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
+    L.pigs_diagonal_estimators.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     L.pigs_selftest_stream_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -439,6 +441,24 @@ class PigsContext:
         _chk(self.L, self.L.pigs_structure_batch(self.h, n, None if w is None else _i(w), int(ib), int(Nbin),
                                                  float(rbin), int(Nk), _d(gr), _d(Sk)), "pigs_structure_batch")
         return gr, Sk
+
+    def diagonal_estimators(self, Nbin=0, rbin=0.0, Nk=0, walkers=None, structure=True):
+        """All estimators of a diagonal MC step (vpi.f90:443-469) in one call: returns a dict with
+        E1,K1,V1 (LocalEnergy slice 0), E2,K2,V2 (slice 2Nb), Et,Kt,Vt (ThermEnergy) -- arrays of n -- and, for PBC
+        runs with structure=True, gr (n,Nbin), Sk (n,Nk,dim)."""
+        w = None if walkers is None else _i32(walkers).ravel()
+        n = self.n_walkers if w is None else w.size
+        en = np.empty((n, 9))
+        gr = Sk = None
+        if structure and not self.cfg.trap:
+            gr = np.empty((n, Nbin))
+            Sk = np.empty((n, Nk, self.cfg.dim))
+        _chk(self.L, self.L.pigs_diagonal_estimators(self.h, n, None if w is None else _i(w), int(Nbin), float(rbin), int(Nk),
+                                                     _d(en), None if gr is None else _d(gr), None if Sk is None else _d(Sk)),
+             "pigs_diagonal_estimators")
+        out = {k: en[:, i] for i, k in enumerate(("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt"))}
+        out["gr"], out["Sk"] = gr, Sk
+        return out
 
     # ---- multi-GPU
     def comm_init_rank(self, nranks, rank, unique_id: bytes):

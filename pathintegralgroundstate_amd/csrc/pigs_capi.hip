@@ -298,11 +298,23 @@ static int check_cm(pigs_ctx *c)
     return PIGS_OK;
 }
 
+// every entry point that waits for the stream and then hands state of the walkers to the caller (worldlines, counters,
+// events, generator, estimators) ends here: after a time-out in pigs_cm.hip none of it may be returned as if it were valid
+static int sync_checked(pigs_ctx *c)
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return check_cm(c);
+}
+#define SYNC_CHECKED(c)                          \
+    do {                                         \
+        const int rc_ = sync_checked(c);         \
+        if (rc_) return rc_;                     \
+    } while (0)
+
 int pigs_sync(pigs_ctx *c)
 {
     int rc = check_ctx(c); if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return check_cm(c);
+    return sync_checked(c);
 }
 
 int pigs_stream(pigs_ctx *c, void **s)
@@ -329,6 +341,10 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
         c->cm_split = value;
         return PIGS_OK;
     }
+    if (!strcmp(key, "cm_fault")) {             // TEST ONLY: force the time-out path of the TranslateChain exchange (pigs_cm.hip)
+        c->sweep.cm_fault = value != 0;
+        return PIGS_OK;
+    }
     if (!strcmp(key, "sweep_threads")) {
         if (value != 256 && value != 512 && value != 768 && value != 1024) return fail(PIGS_ERR_ARG, "sweep_threads=%d", value);
         c->sweep_threads = value;
@@ -347,7 +363,7 @@ int pigs_selftest_fastmath(pigs_ctx *c, int32_t blocks, int32_t iters, uint64_t 
     HIPCHK(launch_selftest_fastmath(c->P, 0x1234567ull, blocks, iters, d, c->stream));
     unsigned long long h[4];
     HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     HIPCHK(hipFree(d));
     for (int i = 0; i < 4; ++i) bad[i] = h[i];
     return PIGS_OK;
@@ -439,7 +455,7 @@ static int upload_range(pigs_ctx *c, int w0, int nw, const double *raw)
         HIPCHK(hipMemcpyAsync(c->d_stage.p, raw + c->raw_doubles * a, c->raw_doubles * m * sizeof(double),
                               hipMemcpyHostToDevice, c->stream));
         HIPCHK(launch_pack(c->P, c->d_paths, c->d_stage.p, w0 + a, m, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SYNC_CHECKED(c);
     }
     return PIGS_OK;
 }
@@ -456,7 +472,7 @@ static int download_range(pigs_ctx *c, int w0, int nw, double *raw)
         HIPCHK(launch_unpack(c->P, c->d_paths, c->d_stage.p, w0 + a, m, c->stream));
         HIPCHK(hipMemcpyAsync(raw + c->raw_doubles * a, c->d_stage.p, c->raw_doubles * m * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SYNC_CHECKED(c);
     }
     return PIGS_OK;
 }
@@ -501,7 +517,7 @@ static int delta_action_host(pigs_ctx *c, int64_t n, const int32_t *walker, cons
                                parts ? c->d_parts.p : nullptr, s));
     if (DeltaS) HIPCHK(hipMemcpyAsync(DeltaS, c->d_out.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (parts) HIPCHK(hipMemcpyAsync(parts, c->d_parts.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -541,7 +557,7 @@ int pigs_stage_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **walker,
     if (cap < 1 || cap > 0x7fffffff || keep < 0 || !walker || !ip || !ib || !xnew || !xold || !DeltaS)
         return fail(PIGS_ERR_ARG, "bad stage_reserve arguments");
     if (cap > c->st_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SYNC_CHECKED(c);
         const size_t d = c->P.dim, k = (size_t)(keep < c->st_cap ? keep : c->st_cap);
         HIPCHK(c->st_w.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
         HIPCHK(c->st_ip.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
@@ -566,7 +582,7 @@ int pigs_delta_action_staged(pigs_ctx *c, int64_t n)
                                (const int32_t *)c->st_w.d, (const int32_t *)c->st_ip.d, (const int32_t *)c->st_ib.d,
                                (const double *)c->st_xn.d, (const double *)c->st_xo.d, (double *)c->st_out.d,
                                nullptr, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -575,7 +591,7 @@ int pigs_commit_reserve(pigs_ctx *c, int64_t cap, int64_t keep, int32_t **walker
     int rc = check_ctx(c); if (rc) return rc;
     if (cap < 1 || cap > 0x7fffffff || keep < 0 || !walker || !ip || !ib || !x) return fail(PIGS_ERR_ARG, "bad commit_reserve arguments");
     if (cap > c->cs_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SYNC_CHECKED(c);
         const size_t d = c->P.dim, k = (size_t)(keep < c->cs_cap ? keep : c->cs_cap);
         HIPCHK(c->cs_w.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
         HIPCHK(c->cs_ip.reserve(cap * sizeof(int32_t), k * sizeof(int32_t)));
@@ -621,7 +637,7 @@ int pigs_commit_beads(pigs_ctx *c, int64_t n, const int32_t *walker, const int32
     HIPCHK(hipMemcpyAsync(c->d_ib.p, ib, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_xnew.p, x, nd * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(launch_commit_beads(c->P, c->d_paths, n, c->d_walker.p, c->d_ip.p, c->d_ib.p, c->d_xnew.p, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -632,7 +648,7 @@ int pigs_swap_tails(pigs_ctx *c, int32_t walker, int32_t iw, int32_t ik)
         return fail(PIGS_ERR_ARG, "swap_tails(walker=%d, iw=%d, ik=%d) out of range", walker, iw, ik);
     if (iw == ik) return PIGS_OK;
     HIPCHK(launch_swap_tails(c->P, c->d_paths, walker, iw, ik, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -732,7 +748,7 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
         mt_block_to_device(624, seedw, &st[w * kRngWords]);
     }
     HIPCHK(hipMemcpyAsync(c->d_rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     c->sampler_ready = true;
     return PIGS_OK;
 }
@@ -745,7 +761,7 @@ int pigs_sampler_set_rng(pigs_ctx *c, int32_t walker, int32_t mti, const int32_t
     uint32_t st[kRngWords];
     mt_block_to_device(mti, (const uint32_t *)mt, st);
     HIPCHK(hipMemcpyAsync(c->d_rng + (size_t)walker * kRngWords, st, sizeof st, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -756,7 +772,7 @@ int pigs_sampler_get_rng(pigs_ctx *c, int32_t walker, int32_t *mti, int32_t mt[6
     if (walker < 0 || walker >= c->n_walkers || !mt || !mti) return fail(PIGS_ERR_ARG, "bad rng request");
     uint32_t st[kRngWords];
     HIPCHK(hipMemcpyAsync(st, c->d_rng + (size_t)walker * kRngWords, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     memcpy(mt, st + 624, 624 * sizeof(uint32_t));                    // block form: what mtsavef would hold
     *mti = (int32_t)st[1248];
     return PIGS_OK;
@@ -843,7 +859,7 @@ int pigs_sampler_counters16(pigs_ctx *c, int64_t *cnt)
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready || !cnt) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
     HIPCHK(hipMemcpyAsync(cnt, c->d_counters, (size_t)c->n_walkers * kCounters * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -863,7 +879,7 @@ int pigs_sampler_get_worm(pigs_ctx *c, int32_t *isopen, int32_t *iworm, double *
     if (!c->sampler_ready || !isopen || !iworm || !xend) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
     std::vector<double> h((size_t)c->n_walkers * kWormDoubles);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_worm, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     const int d = c->P.dim;
     for (int w = 0; w < c->n_walkers; ++w) {
         isopen[w] = (int32_t)h[(size_t)w * kWormDoubles];
@@ -886,7 +902,7 @@ int pigs_sampler_set_worm(pigs_ctx *c, const int32_t *isopen, const int32_t *iwo
         for (int t = 0; t < 2 * d; ++t) h[(size_t)w * kWormDoubles + 2 + t] = xend[(size_t)w * 2 * d + t];
     }
     HIPCHK(hipMemcpyAsync(c->d_worm, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -903,7 +919,7 @@ int pigs_sampler_events(pigs_ctx *c, int32_t *events)
     int rc = check_ctx(c); if (rc) return rc;
     if (!c->sampler_ready || !events) return fail(PIGS_ERR_ARG, "pigs_sampler_init first / null output");
     HIPCHK(hipMemcpyAsync(events, c->d_evlog, (size_t)c->n_walkers * c->sweep.ev_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -923,7 +939,7 @@ int pigs_sampler_nrho(pigs_ctx *c, double *nrho, const int32_t *reset)
             w = e;
         }
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -935,7 +951,7 @@ int pigs_slice_download(pigs_ctx *c, int32_t ib, double *R)
     HIPCHK(c->d_stage.reserve(n));
     HIPCHK(launch_slice_gather(c->P, c->d_paths, ib, c->d_stage.p, c->stream));
     HIPCHK(hipMemcpyAsync(R, c->d_stage.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 
@@ -953,7 +969,7 @@ int pigs_potential_energy_slice(pigs_ctx *c, int32_t walker, int32_t ib, int32_t
     HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, c->d_VTimg, 1, c->d_slotw.p, c->d_slotb.p, want_F2 ? 2 : 0, 0, c->d_slices.p, s));
     double h[3];
     HIPCHK(hipMemcpyAsync(h, c->d_slices.p, sizeof h, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     *Pot = h[0];
     if (F2) *F2 = want_F2 ? h[1] : 0.0;
     return PIGS_OK;
@@ -983,7 +999,7 @@ int pigs_therm_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, doub
     HIPCHK(hipMemcpyAsync(E, c->d_res.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(Ec, c->d_res.p + n, n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(Ep, c->d_res.p + 2 * (size_t)n, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));   // sw/sb must outlive the async copies
+    SYNC_CHECKED(c);   // sw/sb must outlive the async copies
     return PIGS_OK;
 }
 
@@ -1007,7 +1023,7 @@ int pigs_local_energy_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, int3
     HIPCHK(launch_local_energy(c->P, c->d_paths, c->d_VT, c->d_WF, n, c->d_slotw.p, ib, c->d_res.p, s));
     std::vector<double> h((size_t)n * 3);
     HIPCHK(hipMemcpyAsync(h.data(), c->d_res.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     for (int i = 0; i < n; ++i) { E[i] = h[3 * i]; Kin[i] = h[3 * i + 1]; Pot[i] = h[3 * i + 2]; }
     return PIGS_OK;
 }
@@ -1033,7 +1049,62 @@ int pigs_structure_batch(pigs_ctx *c, int32_t n, const int32_t *walkers, int32_t
     HIPCHK(launch_structure(c->P, c->d_paths, n, c->d_slotw.p, ib, Nbin, rbin, Nk, c->d_res.p, c->d_res.p + ng, s));
     HIPCHK(hipMemcpyAsync(gr, c->d_res.p, ng * sizeof(double), hipMemcpyDeviceToHost, s));
     if (ns) HIPCHK(hipMemcpyAsync(Sk, c->d_res.p + ng, ns * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
+    return PIGS_OK;
+}
+
+// ---- all diagonal-sector estimators of one MC step in one call ------------------------------
+// What vpi.f90:443-469 evaluates after a diagonal step -- LocalEnergy at slices 0 and 2Nb (K4), ThermEnergy (K2/K3),
+// g(r) and S(k) at slice Nb (K7) -- for n walkers: one upload of the slot lists, five launches, ONE result copy, one
+// synchronisation (the separate entry points cost four round trips: ~1.6 ms per step of 128 walkers in round 2's bench).
+// en[9*i ..] = E,Kin,Pot (slice 0), E,Kin,Pot (slice 2Nb), E,Ec,Ep (ThermEnergy) of walker i; gr (n x Nbin) and
+// Sk (n x Nk x dim) may both be NULL (trapped systems: vpi.f90:466 computes them for PBC runs only).
+int pigs_diagonal_estimators(pigs_ctx *c, int32_t n, const int32_t *walkers, int32_t Nbin, double rbin, int32_t Nk,
+                             double *en, double *gr, double *Sk)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0 || !en) return fail(PIGS_ERR_ARG, "n=%d / null output", n);
+    if (n == 0) return PIGS_OK;
+    const bool structure = gr || Sk;
+    if (structure && (!gr || !Sk || Nbin < 1 || Nk < 0 || !(rbin > 0.0))) return fail(PIGS_ERR_ARG, "bad structure request");
+    if (structure && c->P.trap) return fail(PIGS_ERR_UNSUPPORTED, "structural estimators are defined for PBC runs only (vpi.f90:466)");
+    const int ns = 2 * c->P.Nb;                       // ThermEnergy: slices 0..2Nb-1 (Q8)
+    const size_t nslot = (size_t)n * ns;
+    // slot lists: [0, nslot) the ThermEnergy slices, [nslot, nslot + n) the walkers themselves (K4, K7)
+    std::vector<int32_t> sw(nslot + n), sb(nslot);
+    for (int i = 0; i < n; ++i) {
+        const int w = walkers ? walkers[i] : i;
+        if (w < 0 || w >= c->n_walkers) return fail(PIGS_ERR_ARG, "walker %d out of range", w);
+        for (int b = 0; b < ns; ++b) { sw[(size_t)i * ns + b] = w; sb[(size_t)i * ns + b] = b; }
+        sw[nslot + i] = w;
+    }
+    const size_t ng = structure ? (size_t)n * Nbin : 0, nk = structure ? (size_t)n * Nk * c->P.dim : 0;
+    // result block: [LocalEnergy slice 0: 3n][LocalEnergy slice 2Nb: 3n][E n][Ec n][Ep n][gr][Sk]
+    const size_t nres = (size_t)9 * n + ng + nk;
+    HIPCHK(c->d_slotw.reserve(nslot + n)); HIPCHK(c->d_slotb.reserve(nslot));
+    HIPCHK(c->d_slices.reserve(nslot * 3)); HIPCHK(c->d_res.reserve(nres));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_slotw.p, sw.data(), sw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_slotb.p, sb.data(), sb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    double *r = c->d_res.p;
+    const int32_t *dw = c->d_slotw.p + nslot;
+    HIPCHK(launch_local_energy(c->P, c->d_paths, c->d_VT, c->d_WF, n, dw, 0, r, s));
+    HIPCHK(launch_local_energy(c->P, c->d_paths, c->d_VT, c->d_WF, n, dw, 2 * c->P.Nb, r + 3 * (size_t)n, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_paths, c->d_VT, c->d_VTimg, (int)nslot, c->d_slotw.p, c->d_slotb.p, 1, 1, c->d_slices.p, s));
+    HIPCHK(launch_therm_combine(c->P, n, c->d_slices.p, r + 6 * (size_t)n, r + 7 * (size_t)n, r + 8 * (size_t)n, s));
+    if (structure)
+        HIPCHK(launch_structure(c->P, c->d_paths, n, dw, c->P.Nb, Nbin, rbin, Nk, r + 9 * (size_t)n, r + 9 * (size_t)n + ng, s));
+    std::vector<double> h(nres);
+    HIPCHK(hipMemcpyAsync(h.data(), r, nres * sizeof(double), hipMemcpyDeviceToHost, s));
+    SYNC_CHECKED(c);
+    for (int i = 0; i < n; ++i) {
+        for (int q = 0; q < 3; ++q) { en[9 * i + q] = h[3 * i + q]; en[9 * i + 3 + q] = h[3 * (size_t)n + 3 * i + q]; }
+        en[9 * i + 6] = h[6 * (size_t)n + i]; en[9 * i + 7] = h[7 * (size_t)n + i]; en[9 * i + 8] = h[8 * (size_t)n + i];
+    }
+    if (structure) {
+        memcpy(gr, h.data() + 9 * (size_t)n, ng * sizeof(double));
+        if (nk) memcpy(Sk, h.data() + 9 * (size_t)n + ng, nk * sizeof(double));
+    }
     return PIGS_OK;
 }
 
@@ -1120,7 +1191,7 @@ int pigs_estimators_allreduce(pigs_ctx *c, double *vec, int32_t n)
     const char *err = pigs_comm_allreduce_sum_f64(c->comm, c->d_res.p, n, s);
     if (err) return fail(PIGS_ERR_COMM, "%s", err);
     HIPCHK(hipMemcpyAsync(vec, c->d_res.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    SYNC_CHECKED(c);
     return PIGS_OK;
 }
 

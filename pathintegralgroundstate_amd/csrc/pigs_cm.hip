@@ -152,7 +152,8 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
             // there only after the others published the move in between, i.e. after they finished reading this one
             const unsigned int tag = seq0 + n_try;
             unsigned long long *X = xch + ((size_t)w * 2 + (n_try & 1)) * (size_t)M * 2;
-            if (tid < nbo) {
+            const int spin_limit = sp.cm_fault ? 2048 : kCmSpinLimit;
+            if (tid < nbo && !(sp.cm_fault && h == H - 1)) {          // (cm_fault: this range's values never arrive)
                 const unsigned long long v = (unsigned long long)__double_as_longlong(dS[b0 + tid]);
                 const unsigned long long hi = (unsigned long long)tag << 32;
                 __hip_atomic_store(&X[(size_t)(b0 + tid) * 2],     hi | (v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
                     lo = __hip_atomic_load(&X[(size_t)b * 2],     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hi = __hip_atomic_load(&X[(size_t)b * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (((unsigned int)(lo >> 32) == tag && (unsigned int)(hi >> 32) == tag) || *(volatile int *)&ctl[2]) break;
-                    if (++spins > kCmSpinLimit) {                     // give up once, for the whole workgroup and the rest of the launch
+                    if (++spins > spin_limit) {                     // give up once, for the whole workgroup and the rest of the launch
                         *(volatile int *)&ctl[2] = 1;
                         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
                 const double e = exp(a);
                 if (!(e >= 1.0)) { ok = e >= mt_real(mt[ring_w(pos)]); took = 1; }
             }
+            if (ctl[2]) ok = 0;                                       // an exchange timed out: the sum is garbage, nothing more is committed
             ctl[0] = ok; ctl[1] = took;
         }
         __syncthreads();

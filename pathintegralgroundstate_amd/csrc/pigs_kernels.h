@@ -64,7 +64,9 @@ struct SweepParams {
     int32_t open_attempt, parts, worm, swapping;  // worm: CWorm > 0 (open/close/swap sector sampled); parts: sections of the
                                                   // step a launch runs (1 open/close attempt, 2 diagonal moves, 4 worm moves)
     int32_t Nobdm, Nbin, Npw, staging;            // staging: sampling = 'sta' in the diagonal sector
-    int32_t ev_ints, pad1;                        // ints per walker of the event log: max(kEvInts, 4 + 2*(1+Nobdm))
+    int32_t ev_ints, cm_fault;                    // ints per walker of the event log: max(kEvInts, 4 + 2*(1+Nobdm)); cm_fault: TEST
+                                                  // ONLY (tuning key "cm_fault"): the last range of every walker in k_cm withholds
+                                                  // its Delta S and waiting workgroups give up after 2048 polls (forces the time-out path)
     double  delta_cm, log_cworm_density, rbin;
 };
 hipError_t launch_sweep(const DevParams &P, const SweepParams &sp, int threads, double *paths, const double *VT,

@@ -320,6 +320,19 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_structure_batch
 
+     ! every estimator of a diagonal MC step in one call (reference vpi.f90:443-469): en(1:3,i) = LocalEnergy at slice 0,
+     ! en(4:6,i) at slice 2Nb, en(7:9,i) = ThermEnergy of walker walkers(i); gr / Sk = c_null_ptr: no structural estimators
+     function pigs_diagonal_estimators(ctx,n,walkers,Nbin,rbin,Nk,en,gr,Sk) bind(C,name='pigs_diagonal_estimators') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value             :: ctx
+       integer(c_int32_t), value      :: n,Nbin,Nk
+       integer(c_int32_t), intent(in) :: walkers(*)
+       real(c_double), value          :: rbin
+       real(c_double)                 :: en(9,*)
+       type(c_ptr), value             :: gr,Sk
+       integer(c_int) :: rc
+     end function pigs_diagonal_estimators
+
      function pigs_sampler_event_ints(ctx,n) bind(C,name='pigs_sampler_event_ints') result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: ctx

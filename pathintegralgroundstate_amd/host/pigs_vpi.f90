@@ -234,7 +234,8 @@ contains
   logical :: lflag
   integer(8) :: c0,c1,crate
   type(pigs_sweep_params) :: swp_par
-  real(8), allocatable :: gr_inc(:,:),sk_inc(:,:,:)
+  real(8), allocatable, target :: gr_inc(:,:),sk_inc(:,:,:)
+  real(8), allocatable :: en9(:,:)
   integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
   integer(c_int32_t), allocatable :: dev_open(:),dev_iworm(:),dev_ev(:,:),dev_reset(:)
   real(8), allocatable :: dev_nrho(:,:,:)
@@ -340,7 +341,7 @@ contains
   end do
 
   allocate (ipv(NW),iupd(NW),partner(NW),diag_list(NW),act(NW),isopen0(NW),swp(NW),wl(NW))
-  allocate (E1(NW),E2(NW),K1(NW),P1(NW),Et(NW),Kt(NW),Pt(NW))
+  allocate (E1(NW),E2(NW),K1(NW),P1(NW),Et(NW),Kt(NW),Pt(NW),en9(9,NW))
   allocate (acc_cm(NW),acc_bd(NW),acc_head(NW),acc_tail(NW),acc_cm_half(NW),acc_bd_half(NW))
   allocate (acc_head_half(NW),acc_tail_half(NW),acc_open(NW),acc_close(NW),acc_swap(NW))
   allocate (try_open(NW),try_close(NW),try_swap(NW),try_cm(NW),try_stag(NW),try_cm_half(NW),try_stag_half(NW))
@@ -512,16 +513,19 @@ contains
            end if
         end do
         if (nd>0) then
-           if (device_sampler) then
-              if (.not. trap) call pigs_check(pigs_structure_batch(ctx,int(nd,c_int32_t),wl,int(Nb,c_int32_t), &
-                   & int(Nbin,c_int32_t),rbin,int(Nk,c_int32_t),gr_inc,sk_inc),'pigs_structure_batch')
+           ! one call, one synchronisation: LocalEnergy x2 (K4), ThermEnergy (K2/K3) and -- device-resident sampler, PBC --
+           ! g(r), S(k) on the device (K7); the host-driven sampler keeps the structural estimators on its mirror
+           if (device_sampler .and. .not. trap) then
+              call pigs_check(pigs_diagonal_estimators(ctx,int(nd,c_int32_t),wl,int(Nbin,c_int32_t),rbin,int(Nk,c_int32_t), &
+                   & en9,c_loc(gr_inc),c_loc(sk_inc)),'pigs_diagonal_estimators')
            else
-              call sampler_flush(s)
+              if (.not. device_sampler) call sampler_flush(s)
+              call pigs_check(pigs_diagonal_estimators(ctx,int(nd,c_int32_t),wl,0_c_int32_t,0.d0,0_c_int32_t, &
+                   & en9,c_null_ptr,c_null_ptr),'pigs_diagonal_estimators')
            end if
-           call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,0_c_int32_t,E1,K1,P1),'pigs_local_energy_batch')
-           call pigs_check(pigs_local_energy_batch(ctx,int(nd,c_int32_t),wl,int(2*Nb,c_int32_t),E2,K1,P1), &
-                & 'pigs_local_energy_batch')
-           call pigs_check(pigs_therm_energy_batch(ctx,int(nd,c_int32_t),wl,Et,Kt,Pt),'pigs_therm_energy_batch')
+           do i=1,nd
+              E1(i) = en9(1,i); E2(i) = en9(4,i); Et(i) = en9(7,i); Kt(i) = en9(8,i); Pt(i) = en9(9,i)
+           end do
            !$omp parallel do schedule(dynamic,1) private(w,E,Pot,Kin) num_threads(min(nd,16))
            do i=1,nd
               w = diag_list(i)

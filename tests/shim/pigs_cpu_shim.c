@@ -284,3 +284,17 @@ int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n)
 }
 int pigs_selftest_fastmath(pigs_ctx *c, int32_t b, int32_t i, uint64_t bad[4]) { (void)c; (void)b; (void)i; memset(bad, 0, 32); return PIGS_OK; }
 int pigs_selftest_stream_read(pigs_ctx *c, int32_t reps, double *bytes, double *seconds) { (void)c; (void)reps; *bytes = 0.0; *seconds = 1.0; return PIGS_OK; }
+int pigs_selftest_log(pigs_ctx *c, int64_t n, uint64_t seed, uint64_t *bad, double *x) { (void)c; (void)n; (void)seed; *bad = 0; if (x) *x = 0.0; return PIGS_OK; }
+
+int pigs_diagonal_estimators(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t Nbin, double rbin, int32_t Nk,
+                             double *en, double *gr, double *Sk)
+{
+    for (int i = 0; i < n; ++i) {
+        const int32_t w = ws ? ws[i] : i;
+        pigs_local_energy_batch(c, 1, &w, 0, &en[9 * i], &en[9 * i + 1], &en[9 * i + 2]);
+        pigs_local_energy_batch(c, 1, &w, 2 * c->s.Nb, &en[9 * i + 3], &en[9 * i + 4], &en[9 * i + 5]);
+        pigs_therm_energy_batch(c, 1, &w, &en[9 * i + 6], &en[9 * i + 7], &en[9 * i + 8]);
+    }
+    if (gr && Sk) return pigs_structure_batch(c, n, ws, c->s.Nb, Nbin, rbin, Nk, gr, Sk);
+    return PIGS_OK;
+}

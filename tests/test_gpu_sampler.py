@@ -361,3 +361,76 @@ def test_uniform_of_exactly_one_stays_inside_the_chain(gpu_lib, oracle, sampling
         hit += not same_bits(got[0], base[0])
     assert hit > 40                                   # the poisoned word was consumed in most runs
     ctx.close()
+
+
+def test_translate_chain_exchange_time_out_is_an_error_not_a_result(gpu_lib, oracle):
+    """pigs_cm.hip runs a walker's TranslateChain on H cooperating workgroups that wait for each other's Delta S in a
+    plain (non-cooperative) launch.  The waiting is bounded; this forces the bound once (test-only tuning key
+    "cm_fault": every walker's last range withholds its values, the waiting workgroups give up after 2048 polls) and
+    asserts what the library promises then: the launch ends (bounded run time), nothing is committed after the time-out,
+    the next synchronisation returns PIGS_ERR_HIP, pigs_sampler_step refuses to go on, and no entry point hands out the
+    context's state (worldlines, counters, estimators) as if it were valid."""
+    import time
+    from oracle.pyoracle import System
+    cfg = SystemConfig(dim=3, Np=48, Nb=16, density=0.3, dt=5e-3, Rm=1.2, Nlev=4, Nstag=1, Lstag=8, CMFreq=1, delta_cm=0.3)
+    S = System(dim=3, Np=48, Nb=16, density=0.3, dt=5e-3, Rm=1.2)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = 3
+    ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+    try:
+        ctx.sampler_init()
+        ctx.set_tuning("cm_split", 2)
+        Paths = []
+        for w in range(W):
+            P, g = oracle.init_path(S, 700 + w)
+            Paths.append(P)
+            ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+        ctx.upload_all(np.stack(Paths))
+        ctx.sampler_step(1)                       # healthy step first: the exchange works
+        ctx.sync()
+        before = ctx.download_all()
+        ctx.set_tuning("cm_fault", 1)
+        t0 = time.perf_counter()
+        ctx.sampler_step(2)                       # the launch itself is asynchronous and succeeds
+        with pytest.raises(gpu_lib.PigsError, match="timed out"):
+            ctx.sync()
+        assert time.perf_counter() - t0 < 5.0     # bounded: one give-up per workgroup, then nobody waits
+        for call in (lambda: ctx.sampler_step(3), ctx.download_all, ctx.sampler_counters16, ctx.therm_energy_batch,
+                     lambda: ctx.sampler_get_rng(0), lambda: ctx.diagonal_estimators(structure=False)):
+            with pytest.raises(gpu_lib.PigsError, match="timed out"):
+                call()
+        ctx.set_tuning("cm_fault", 0)             # the context stays invalid: it has to be recreated
+        with pytest.raises(gpu_lib.PigsError, match="timed out"):
+            ctx.sampler_step(3)
+    finally:
+        ctx.close()
+    assert before.shape == (W, cfg.M, cfg.Np, 3)
+
+
+def test_diagonal_estimators_one_call_equals_the_separate_calls(gpu_lib, oracle):
+    """pigs_diagonal_estimators (one synchronisation per MC step) returns exactly what LocalEnergy x2, ThermEnergy and the
+    structure call return one by one -- same kernels, same bits -- for all walkers and for a subset."""
+    from oracle.pyoracle import System
+    cfg = SystemConfig(dim=3, Np=64, Nb=12, density=0.3, dt=5e-3, Rm=1.2)
+    S = System(dim=3, Np=64, Nb=12, density=0.3, dt=5e-3, Rm=1.2)
+    VT, WF = gpu_lib.build_tables(cfg)
+    rng = np.random.default_rng(5)
+    W = 5
+    Paths = []
+    for w in range(W):
+        P, _ = oracle.init_path(S, 40 + w)
+        P = P + rng.normal(0, 0.15, P.shape)
+        L = S.Lbox[0]
+        P = np.where(P > L / 2, P - L, P)
+        Paths.append(np.where(P < -L / 2, P + L, P))
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(np.stack(Paths))
+        for walkers in (None, np.array([3, 1], np.int32)):
+            one = ctx.diagonal_estimators(40, cfg.rcut / 40, 7, walkers=walkers)
+            a = ctx.local_energy_batch(0, walkers)
+            b = ctx.local_energy_batch(2 * cfg.Nb, walkers)
+            t = ctx.therm_energy_batch(walkers)
+            gr, Sk = ctx.structure_batch(cfg.Nb, 40, cfg.rcut / 40, 7, walkers)
+            for k, v in zip(("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt"), list(a) + list(b) + list(t)):
+                assert same_bits(one[k], v), k
+            assert same_bits(one["gr"], gr) and same_bits(one["Sk"], Sk)
