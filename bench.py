@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse "
                                                       "the multi-process path on a one-GPU machine)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-mc", action="store_true", help="skip the device-resident sampler legs (profiling runs of K1 only)")
     ap.add_argument("--mc-steps", type=int, default=14, help="MC steps per timed leg of the device-resident sampler (>= 0.5 s at 128 walkers)")
     ap.add_argument("--mc-large-walkers", type=int, default=1024, help="walkers of the second sampler leg (0: skip)")
     args = ap.parse_args()
@@ -358,6 +359,8 @@ def main():
     # bisection}, stock vpi.in schedule CMFreq=1 Nstag=5 Nlev=4) with no host in the loop.
     mc = None
     try:
+        if args.no_mc:
+            raise api.PigsError("skipped (--no-mc)")
         mcfg = SystemConfig(dim=3, Np=args.np, Nb=args.nb, density=0.365, dt=5e-3, Rm=1.2, Nlev=4, Nstag=5,
                             Lstag=32, CMFreq=1, delta_cm=0.12)
         ctx.sampler_init(Nlev=mcfg.Nlev, Nstag=mcfg.Nstag, CMFreq=1, Lstag=min(32, args.nb), delta_cm=mcfg.delta_cm_eff)

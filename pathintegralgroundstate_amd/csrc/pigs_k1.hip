@@ -509,8 +509,8 @@ __device__ __forceinline__ void pipe2_pass(const DevParams &P, PipeTab VT, const
     }
     const double r2o = min_image_rn<DIM>(dold, P);
     const double r2n = min_image_rn<DIM>(dn, P);
-    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
-    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
+    pipe_pair<DIM, CLS, false>(P, VT, WF, floor_r2(r2n), valid && r2n <= P.rcut2, dn, A);
+    pipe_pair<DIM, CLS, true>(P, VT, WF, floor_r2(r2o), valid && r2o <= P.rcut2, dold, A);
     __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -367,6 +367,12 @@ struct PipeTab {
     int zc;
 };
 
+// r2 of a lane measuring the moved particle against its own row is exactly 0 and v_rsq_f64(0) = +Inf would poison the
+// (masked) lane's lookup with NaN.  r2 + 1e-300 is r2 itself, bit for bit, for every r2 >= 1e-284 (the addend is far below
+// half an ulp) and 1e-300 for r2 = 0: ONE v_add_f64 where fmax(r2, 1e-300) compiles to two v_max_f64 (the first
+// canonicalises a possible signalling NaN) -- 2 of the 74 (even) / 102 (odd) instructions of a pass.
+__device__ __forceinline__ double floor_r2(double r2) { return r2 + 1e-300; }
+
 // one distance, branch-free and weight-free (see PipeTab).  r2 must be finite and > 0 on every lane (the caller
 // floors it at 1e-300: a lane measuring the moved particle against its own row has r2 = 0).
 //   r   = sqrt(r2) from v_rsq_f64 (2^-24) + one coupled Newton step + one residual correction (< 1 ulp)
@@ -405,9 +411,13 @@ __device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const 
     if (CLS == CLS_END) {                                                 // LogWF stays in global memory (2 of 161 beads)
         double u;
         if (P.wf_table) {
+#ifdef PIGS_EXP_NOWF                                                          // timing experiment only: no LogWF gather
+            u = in ? f : 0.0;
+#else
             const double *U = WF + (in ? it : 0);
             const double u0 = U[0], u1 = U[1];
             u = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;              // (1-f)*(-Inf) keeps the -Inf head (Q4)
+#endif
         } else {
             u = in ? log_psi(0, P.Rm, g) : 0.0;                               // analytic trial function (wf_table = F)
         }
@@ -435,8 +445,8 @@ __device__ __forceinline__ void pipe_pass_at(const DevParams &P, PipeTab VT, con
     }
     const double r2o = min_image_rn<DIM>(dold, P);
     const double r2n = min_image_rn<DIM>(dn, P);
-    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2n, 1e-300), valid && r2n <= P.rcut2, dn, A);
-    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2o, 1e-300), valid && r2o <= P.rcut2, dold, A);
+    pipe_pair<DIM, CLS, false>(P, VT, WF, floor_r2(r2n), valid && r2n <= P.rcut2, dn, A);
+    pipe_pair<DIM, CLS, true>(P, VT, WF, floor_r2(r2o), valid && r2o <= P.rcut2, dold, A);
     __builtin_amdgcn_sched_barrier(0);                                // two chains in flight (VGPRs)
 }
 
@@ -553,14 +563,14 @@ __device__ __forceinline__ void pipe_task_cls(const DevParams &P, PipeTab VT, co
 #pragma unroll
                     for (int k = 0; k < DIM; ++k) d[k] = xn[k] - rj[m][k];
                     const double r2 = min_image_rn<DIM>(d, P);
-                    pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+                    pipe_pair<DIM, CLS, false>(P, VT, WF, floor_r2(r2), valid && r2 <= P.rcut2, d, A);
                 }
                 if (sides & 2) {
                     double d[DIM];
 #pragma unroll
                     for (int k = 0; k < DIM; ++k) d[k] = xo[k] - rj[m][k];
                     const double r2 = min_image_rn<DIM>(d, P);
-                    pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+                    pipe_pair<DIM, CLS, true>(P, VT, WF, floor_r2(r2), valid && r2 <= P.rcut2, d, A);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -618,14 +628,14 @@ __device__ __forceinline__ void pipe_task_rolled_cls(const DevParams &P, PipeTab
 #pragma unroll
             for (int k = 0; k < DIM; ++k) d[k] = xn[k] - rj[k];
             const double r2 = min_image_rn<DIM>(d, P);
-            pipe_pair<DIM, CLS, false>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+            pipe_pair<DIM, CLS, false>(P, VT, WF, floor_r2(r2), valid && r2 <= P.rcut2, d, A);
         }
         if (sides & 2) {
             double d[DIM];
 #pragma unroll
             for (int k = 0; k < DIM; ++k) d[k] = xo[k] - rj[k];
             const double r2 = min_image_rn<DIM>(d, P);
-            pipe_pair<DIM, CLS, true>(P, VT, WF, __builtin_fmax(r2, 1e-300), valid && r2 <= P.rcut2, d, A);
+            pipe_pair<DIM, CLS, true>(P, VT, WF, floor_r2(r2), valid && r2 <= P.rcut2, d, A);
         }
     }
     if (tsub) { asm volatile("" :: "v"(A.potN), "v"(A.potO)); q2 = __builtin_amdgcn_s_memtime(); }

@@ -244,6 +244,21 @@ RUNS = {
                                Nblock=2, Nstep=4, CWorm="20.0d0", Nobdm=10, Npw=2, big=True),
     "c5_n256_dipolar_s1982": dict(dim=3, Np=256, Nb=160, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
                                   Nblock=2, Nstep=4, CWorm="20.0d0", Nobdm=10, Npw=2, big=True, potential="dipolar"),
+    # ---- BASELINE sizes, LONG: past the cold start.  Every run starts from the reference's own `init`
+    # (so no start state has to be stored: the test replays the warm-up too) and goes on for 50-60 MC steps: at C3 the
+    # first 30 steps are the warm-up during which acceptance and bead spread settle (accepted moves per sweep rise from
+    # ~1 450 to ~1 800), the last 20 are in the regime bench.py times.  C5 with the STOCK CWorm = 0.5: the Aziz run
+    # contains 4 accepted opens and 4 accepted closes (no swap is accepted in liquid 4He at this dt within 200 steps:
+    # 0 of 290 tries), the dipolar run 1 open and >100 accepted swaps (and no close within 200 steps: 0 of 106 tries) --
+    # between them every worm event at N=256, 321 beads.  driver.npz also holds the state at the end of every block.
+    "c3_n256_long_s1982": dict(dim=3, Np=256, Nb=80, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                               Nblock=5, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, big=True),
+    "c3_n256_long_s1983": dict(dim=3, Np=256, Nb=80, seed=1983, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                               Nblock=5, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, big=True),
+    "c5_n256_aziz_long_s1982": dict(dim=3, Np=256, Nb=160, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                                    Nblock=6, Nstep=10, CWorm="0.5d0", Nobdm=10, Npw=2, big=True),
+    "c5_n256_dipolar_long_s1982": dict(dim=3, Np=256, Nb=160, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,
+                                       Nblock=6, Nstep=10, CWorm="0.5d0", Nobdm=10, Npw=2, big=True, potential="dipolar"),
 }
 RUN_FILES = ["e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out", "fort.99"]
 BIG_STRIDE = 8           # fixtures of the N=256 runs keep every 8th bead + SHA-256 + per-bead sums
@@ -372,6 +387,48 @@ def make_resume_fixture():
     print("resume fixture written to", dst)
 
 
+def make_crystal_fixture():
+    """crystal = T (reference vpi.f90:99-107, vpi_mod.f90:218-230): particle number, box and density come from
+    config_ini.in, whose remaining lines are the start configuration (every bead of a particle on its lattice site).
+    A 3x3x3 simple-cubic lattice with a seeded jitter at density 0.45; worm sector on.  Reference PROGRAM files +
+    its final worldline; config_ini.in is part of the fixture (it is input data)."""
+    import shutil
+    dst = os.path.join(OUT, "vpi_runs", "he4_crystal")
+    os.makedirs(dst, exist_ok=True)
+    n, dens = 3, 0.45
+    Np = n ** 3
+    L = (Np / dens) ** (1.0 / 3.0)
+    rng = np.random.default_rng(27)
+    sites = (np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) * (L / n) - L / 2
+    sites = sites + rng.normal(0, 0.03, sites.shape)
+    cfg = "%d\n%s\n%.17g\n" % (Np, " ".join("%.17g" % L for _ in range(3)), dens)
+    cfg += "".join(" ".join("%.17g" % x for x in r) + "\n" for r in sites)
+    # the namelist's Np and density are deliberately different: config_ini.in wins (vpi.f90:103-105)
+    kw = dict(dim=3, Np=8, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3, Nblock=4, Nstep=15,
+              CWorm="0.5d0", Nobdm=4, Npw=1, density="0.2d0")
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "config_ini.in"), "w") as f:
+            f.write(cfg)
+        p = dict(dim=3, Np=64, density="0.365d0", trap="F", dt="5.0d-3", Nb=40, seed=1982, sampling="bis", Lstag=16, Nlev=4,
+                 Nstag=5, Nblock=1, Nstep=10, CWorm="0.0d0", Nobdm=0, Npw=0, a_ho="1.0d0", wf_table="T")
+        p.update(kw)
+        txt = VPI_IN.format(**p).replace("trap = F", "crystal = T, trap = F")
+        with open(os.path.join(td, "vpi.in"), "w") as f:
+            f.write(txt)
+        with open(os.path.join(td, "vpi.in")) as fin, open(os.path.join(td, "stdout"), "w") as fo:
+            subprocess.run([REF_VPI], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=td, check=False, timeout=600)
+        M = 2 * kw["Nb"] + 1
+        with open(os.path.join(td, "checkpoint.dat")) as f:
+            lines = f.read().split("\n")
+        vals = np.array([[float(x) for x in ln.split()] for ln in lines[3:3 + Np * M]])
+        P = np.ascontiguousarray(vals.reshape(Np, M, 3).transpose(1, 0, 2))
+        for f in RUN_FILES + ["vpi.in", "config_ini.in"]:
+            if os.path.exists(os.path.join(td, f)):
+                shutil.copy(os.path.join(td, f), os.path.join(dst, f))
+    np.savez_compressed(os.path.join(dst, "final_worldline.npz"), Path=P)
+    print("crystal fixture written to", dst, "files", sorted(os.listdir(dst)))
+
+
 if __name__ == "__main__":
     sys.path.insert(0, OUT)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -381,3 +438,5 @@ if __name__ == "__main__":
         make_runs(set(sys.argv[2:]) or None)
     if what in ("all", "resume"):
         make_resume_fixture()
+    if what in ("all", "crystal"):
+        make_crystal_fixture()

@@ -42,6 +42,7 @@ def drive(ref, S, VT, WF, seed, *, Nblock, Nstep, sampling="bis", Lstag=16, Nlev
                        else ("MoveHeadBisection", "MoveTailBisection", "Bisection"))
     par = Lstag if sampling == "sta" else Nlev
     gstep = 0
+    ckpt_sha, ckpt_mti, ckpt_cnt, ckpt_nev = [], [], [], []
     for iblock in range(1, Nblock + 1):
         bE = np.zeros(3)
         bT = np.zeros(3)
@@ -110,11 +111,19 @@ def drive(ref, S, VT, WF, seed, *, Nblock, Nstep, sampling="bis", Lstag=16, Nlev
             n = float(np.float32(idiag_block))                      # NormalizeAv divides by real(Nitem)
             rows_e.append([iblock, *(bE / n / Np)])
             rows_t.append([iblock, *(bT / n / Np)])
+        # state at the end of every block: a run of the first k blocks must end exactly here (prefix tests of the
+        # long trajectories: the host-driven sampler does not have to run all of them)
+        ckpt_sha.append(np.frombuffer(hashlib.sha256(np.ascontiguousarray(Path).tobytes()).digest(), np.uint8).copy())
+        ckpt_mti.append(int(ref.rng_get_state()[0]))
+        ckpt_cnt.append([cnt[k] for k in COUNTER_NAMES])
+        ckpt_nev.append(len(events))
     mti, mt = ref.rng_get_state()
     return dict(Path=Path.copy(), xend=xend.copy(), isopen=int(isopen), iworm=int(iworm),
                 steps=np.array(steps), block_e=np.array(rows_e).reshape(-1, 4), block_t=np.array(rows_t).reshape(-1, 4),
                 counters=np.array([cnt[k] for k in COUNTER_NAMES], np.int64), events=np.array(events, np.int64).reshape(-1, 3),
-                nrho_total=nrho_total, gr_total=gr_total, sk_total=sk_total, mti=np.int32(mti), mt=mt.copy())
+                nrho_total=nrho_total, gr_total=gr_total, sk_total=sk_total, mti=np.int32(mti), mt=mt.copy(),
+                ckpt_sha=np.array(ckpt_sha, np.uint8), ckpt_mti=np.array(ckpt_mti, np.int32),
+                ckpt_counters=np.array(ckpt_cnt, np.int64), ckpt_nevents=np.array(ckpt_nev, np.int64))
 
 
 # order = the 16 counters of the device-resident sampler (pigs_sampler.hip)

@@ -26,6 +26,8 @@ struct pigs_ctx {
     int64_t st_cap, cs_cap;
     void   *group;     /* shim_group of pigs_comm_init_all */
     int     grank;
+    long    n_allreduce;   /* calls of pigs_estimators_allreduce on this context (PIGS_SHIM_TRACE) */
+    long    n_allreduce_nd0; /* ... of which with vec[0] == 0: a block in which this shard had no diagonal step */
 };
 
 static char g_err[256] = "";
@@ -61,6 +63,9 @@ int pigs_ctx_create(const pigs_params *p, const double *VT, const double *WF, in
 int pigs_ctx_destroy(pigs_ctx *c)
 {
     if (!c) return PIGS_OK;
+    if (getenv("PIGS_SHIM_TRACE"))
+        fprintf(stderr, "shim: context rank %d: %ld all-reduce calls, %ld with no diagonal step in the shard\n", c->grank,
+                c->n_allreduce, c->n_allreduce_nd0);
     free(c->VT); free(c->WF); free(c->paths); free(c);
     return PIGS_OK;
 }
@@ -256,6 +261,8 @@ int pigs_comm_init_all(pigs_ctx **c, int32_t n)
 int pigs_estimators_allreduce(pigs_ctx *c, double *v, int32_t n)
 {
     if (!c || !v || n < 0) return PIGS_ERR_ARG;
+    ++c->n_allreduce;
+    if (n > 0 && v[0] == 0.0) ++c->n_allreduce_nd0;
     shim_group *g = (shim_group *)c->group;
     if (!g || g->n == 1) return PIGS_OK;
     pthread_mutex_lock(&g->m);

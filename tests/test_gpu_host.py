@@ -27,7 +27,10 @@ def exe(gpu_lib):
     return os.path.join(HOST, "pigs_vpi")
 
 
-def _run(exe, txt, wd, env=None):
+def _run(exe, txt, wd, env=None, extra_files=()):
+    import shutil
+    for f in extra_files:
+        shutil.copy(f, os.path.join(wd, os.path.basename(f)))
     with open(os.path.join(wd, "vpi.in"), "w") as f:
         f.write(txt)
     with open(os.path.join(wd, "vpi.in")) as fin, open(os.path.join(wd, "stdout.txt"), "w") as fo:
@@ -44,7 +47,7 @@ def _close(mine, ref, rel=1e-10):
     return np.all(np.abs(a - b) <= rel * np.abs(b) + 1.01e-9 * np.abs(b))
 
 
-def _hex_close(hexfile, src, rel=1e-10, mixed=1e-10):
+def _hex_close(hexfile, src, rel=1e-10, mixed=1e-10, nblocks=None):
     """Block energies E K V Et Kt Vt (per particle) of e_vpi*.hex against the 64-bit values of the reference's own
     estimators run in the program's schedule (driver.npz): 1e-10 relative (helpers.block_energy_errors), no printing
     floor.  `mixed` is the bound for the E, K columns: 1e-10 where the worldline is bit-identical (host-driven
@@ -52,7 +55,12 @@ def _hex_close(hexfile, src, rel=1e-10, mixed=1e-10):
     drv = dict(np.load(os.path.join(src, "driver.npz")))
     blocks, rows = read_hex_blocks(hexfile)
     wb, wrows = driver_blocks(drv)
+    if nblocks is not None:                                 # a run of the first `nblocks` blocks of a longer reference run
+        keep = wb <= nblocks
+        wb, wrows = wb[keep], wrows[keep]
     assert np.array_equal(blocks, wb), (blocks, wb)
+    if len(wb) == 0:
+        return True
     em, er = block_energy_errors(rows, wrows)
     assert np.all(er <= rel), er.max()
     assert np.all(em <= mixed), em.max()
@@ -349,3 +357,64 @@ def test_gpu_front_end_sharded_contexts_one_gpu(exe, dev, tmp_path):
         ok = np.isfinite(x)
         assert x.shape == y.shape and np.array_equal(ok, np.isfinite(y))
         assert np.all(np.abs(x - y)[ok] <= 1e-9 * np.abs(x[ok]) + 1e-300), f
+
+
+# ---- long trajectories at the BASELINE sizes (tests/golden/vpi_runs/*_long_*: 50-60 MC steps from the reference's init) ----
+@pytest.mark.parametrize("dev", ["F", "T"])
+def test_gpu_front_end_config3_long_trajectory(exe, dev, tmp_path):
+    """C3, 50 MC steps (30 of warm-up + 20 in the regime bench.py times), two lock-step walkers = the reference chains
+    of seeds 1982 and 1983, host-driven sampler (~18 000 K1 batches per step) and device-resident sampler: final
+    worldlines bit-identical (SHA-256), 64-bit block energies of all five blocks to 1e-10."""
+    src = [os.path.join(RUNS, f"c3_n256_long_s{s_}") for s_ in (1982, 1983)]
+    _run(exe, open(os.path.join(src[0], "vpi.in")).read() +
+         f"&gpu\n n_walkers = 2, device = 0, device_sampler = {dev}, checkpointing = F\n/\n", str(tmp_path))
+    got = np.fromfile(tmp_path / "worldlines_final.bin")
+    for w in range(2):
+        drv = dict(np.load(os.path.join(src[w], "driver.npz")))
+        shape = tuple(int(x) for x in drv["Path_shape"])
+        check_worldline_vs_driver(got.reshape((2,) + shape)[w], drv, None, tol=0.0)
+        assert _hex_close(tmp_path / f"e_vpi.w{w:04d}.hex", src[w])
+
+
+@pytest.mark.parametrize("name", ["c5_n256_aziz_long_s1982", "c5_n256_dipolar_long_s1982"])
+@pytest.mark.parametrize("dev,nblocks", [("F", 2), ("T", 6)])
+def test_gpu_front_end_config5_long_worm_trajectories(exe, name, dev, nblocks, tmp_path):
+    """C5 with the stock CWorm = 0.5.  Device-resident sampler: all 60 steps (Aziz: 4 opens + 4 closes; dipolar: 1 open,
+    > 100 swaps), final worldline bit-identical, OBDM file and permutation histogram as the reference program writes
+    them.  Host-driven sampler (1.2 s per step at this size): the first two blocks = 20 steps, which must end on the
+    reference's state at the end of its block 2 (Aziz: open at step 13, close at 15; dipolar: open at 7, dozens of swaps)."""
+    src = os.path.join(RUNS, name)
+    drv = dict(np.load(os.path.join(src, "driver.npz")))
+    pot = str(drv["potential"])
+    txt = open(os.path.join(src, "vpi.in")).read().replace("Nblock = 6", f"Nblock = {nblocks}")
+    assert f"Nblock = {nblocks}" in txt
+    _run(exe, txt + f"&gpu\n n_walkers = 1, device = 0, device_sampler = {dev}, potential = '{pot}', checkpointing = F\n/\n",
+         str(tmp_path))
+    shape = tuple(int(x) for x in drv["Path_shape"])
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(shape)
+    from helpers import sha256_of
+    assert np.array_equal(sha256_of(got), drv["ckpt_sha"][nblocks - 1]), "worldline differs from the reference's at the end of block %d" % nblocks
+    assert _hex_close(tmp_path / "e_vpi.hex", src, nblocks=nblocks)
+    if nblocks == 6:
+        if os.path.exists(os.path.join(src, "nr_vpi.out")):
+            assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+        if os.path.exists(os.path.join(src, "fort.99")):
+            assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
+
+
+@pytest.mark.parametrize("dev", ["F", "T"])
+def test_gpu_crystal_start_from_config_ini(exe, dev, tmp_path):
+    """crystal = T on the MI355X, both samplers: Np / box / density and the start configuration from config_ini.in
+    (reference vpi.f90:99-107, vpi_mod.f90:218-230) -- worldline bit-identical to the reference program's, block
+    energies as printed, OBDM file and permutation histogram identical."""
+    src = os.path.join(RUNS, "he4_crystal")
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + f"&gpu\n n_walkers = 1, device = 0, device_sampler = {dev}\n/\n",
+         str(tmp_path), extra_files=[os.path.join(src, "config_ini.in")])
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert same_bits(got, want)
+    for f in ("e_vpi.out", "et_vpi.out"):
+        assert _close(tmp_path / f, os.path.join(src, f)), f
+    assert _close(tmp_path / "gr_vpi.out", os.path.join(src, "gr_vpi.out"), rel=1e-9)
+    assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+    assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()

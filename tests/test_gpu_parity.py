@@ -389,6 +389,23 @@ def test_rccl_estimator_allreduce_single_rank(gpu_lib):
             ctx.estimators_allreduce(np.ones(4))
 
 
+def test_a_shard_on_a_missing_gpu_fails_at_once(gpu_lib):
+    """Multi-GPU readiness on a box with fewer GPUs than shards: a context asked for device n_devices (what the front
+    end's shard n_devices+1 would ask for with &gpu n_gpus too large, or a mis-set LOCAL_RANK) is refused by
+    pigs_ctx_create with a message -- at once, before any communicator is set up, so no rank can be left waiting in
+    ncclCommInitAll / ncclCommInitRank for a peer that never comes."""
+    import time
+    t = load_golden("tables_he4_n64")
+    cfg = config_from_golden(t)
+    nd = gpu_lib.device_count()
+    t0 = time.perf_counter()
+    with pytest.raises(gpu_lib.PigsError, match="device"):
+        gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=1, device_id=nd)
+    with pytest.raises(gpu_lib.PigsError, match="device"):
+        gpu_lib.PigsContext(cfg, t["VTable"], t["LogWF"], n_walkers=1, device_id=-1)
+    assert time.perf_counter() - t0 < 5.0
+
+
 def test_host_pointer_batch_rate_is_reported(gpu_lib):
     """PCIe-inclusive form (host pointers): only checks that it works at the bench size and prints its
     rate for DESIGN.md; the bench's `value` is always the resident-input rate."""

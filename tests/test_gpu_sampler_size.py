@@ -174,3 +174,49 @@ def test_k6_small_runs_full_state(gpu_lib, oracle, names, split):
     r = run_k6(gpu_lib, oracle, names, split=split)
     for w in range(len(names)):
         check_against_driver(r, w)
+
+
+# ---- long trajectories at the BASELINE sizes: past the cold start ------------------------------------------------------
+LONG_FORMS = [(None, 0, None), (256, 0, 0), (None, 1, None), (None, 0, 0)]
+
+
+def _check_block_checkpoints(r, w, upto=None):
+    """driver.npz of the long runs holds the reference's state at the end of every block; the last one is the final state."""
+    drv = r["drv"][w]
+    assert np.array_equal(drv["ckpt_sha"][-1], drv["Path_sha256"]) and int(drv["ckpt_mti"][-1]) == int(drv["mti"])
+    assert np.array_equal(drv["ckpt_counters"][-1], drv["counters"])
+
+
+@pytest.mark.parametrize("threads,split,cm", LONG_FORMS)
+def test_k6_config3_long_equilibrating_trajectory(gpu_lib, oracle, threads, split, cm):
+    """C3 (N=256, 161 beads, stock schedule), 50 MC steps from the reference's init for seeds 1982 and 1983: 30 steps of
+    warm-up during which acceptance and bead spread settle, then 20 in the regime bench.py times.  Every form of the
+    sampler: generator state word for word, all counters, final worldline BIT-identical (SHA-256), every step's six
+    energies to 1e-10."""
+    names = ["c3_n256_long_s1982", "c3_n256_long_s1983"]
+    r = run_k6(gpu_lib, oracle, names, threads, split, cm)
+    for w in range(2):
+        drv = r["drv"][w]
+        assert len(drv["steps"]) == 50 and drv["counters"][3] > 20000       # bisection moves accepted: an equilibrating chain
+        _check_block_checkpoints(r, w)
+        worst, rel = check_against_driver(r, w)
+        print(f"walker {w}: step energies max rel = {rel:.2e}")
+
+
+@pytest.mark.parametrize("name", ["c5_n256_aziz_long_s1982", "c5_n256_dipolar_long_s1982"])
+@pytest.mark.parametrize("threads,split,cm", LONG_FORMS)
+def test_k6_config5_long_worm_trajectories(gpu_lib, oracle, name, threads, split, cm):
+    """C5 (N=256, 321 beads, Npw = 2) with the STOCK CWorm = 0.5 for 60 MC steps.  Aziz table: 4 accepted opens and 4
+    accepted closes; dipolar table: 1 open and > 100 accepted swaps (the reference accepts no swap with the Aziz table
+    and no close with the dipolar one within 200 steps at this dt) -- every worm event at this size between the two.
+    Event log identical in order and arguments, generator state, counters, bit-identical worldline and worm ends, OBDM
+    histogram, energies of the diagonal steps."""
+    r = run_k6(gpu_lib, oracle, [name], threads, split, cm)
+    c = r["drv"][0]["counters"]
+    if "aziz" in name:
+        assert c[5] >= 3 and c[7] >= 3                      # accepted opens, closes
+    else:
+        assert c[5] >= 1 and c[13] >= 100                   # accepted opens, swaps
+    _check_block_checkpoints(r, 0)
+    worst, rel = check_against_driver(r, 0)
+    print(f"{name}: step energies max rel = {rel:.2e}")

@@ -19,7 +19,9 @@ RUNS = os.path.join(GOLDEN, "vpi_runs")
 FILES = ["e_vpi.out", "et_vpi.out", "gr_vpi.out", "sk_vpi.out", "nr_vpi.out"]
 
 
-def run_pigs_vpi(exe, vpi_in_text, workdir, env=None):
+def run_pigs_vpi(exe, vpi_in_text, workdir, env=None, extra_files=()):
+    for f in extra_files:                                   # input files next to vpi.in (config_ini.in of a crystal start)
+        shutil.copy(f, os.path.join(workdir, os.path.basename(f)))
     with open(os.path.join(workdir, "vpi.in"), "w") as f:
         f.write(vpi_in_text)
     with open(os.path.join(workdir, "vpi.in")) as fin, open(os.path.join(workdir, "stdout.txt"), "w") as fo:
@@ -99,6 +101,27 @@ def test_host_driven_sampler_lstag_beyond_nb(exe, name, W, tmp_path):
     for f in FILES:
         mine = tmp_path / (f if W == 1 else f.replace(".out", ".w0000.out"))
         assert open(os.path.join(src, f), "rb").read() == open(mine, "rb").read(), f
+
+
+@pytest.mark.parametrize("W", [1, 2])
+def test_crystal_start_from_config_ini(exe, W, tmp_path):
+    """crystal = T (vpi.f90:99-107, vpi_mod.f90:218-230): Np, box and density come from config_ini.in -- the
+    namelist's Np = 8 and density = 0.2 are overridden by the file's 27 particles at 0.45 -- and every bead starts on
+    the particle's lattice site; no random number is spent on the start.  Reference program files byte for byte, final
+    worldline bit-identical; with two walkers each one reads the same lattice (walker 0 = the reference run)."""
+    src = os.path.join(RUNS, "he4_crystal")
+    txt = open(os.path.join(src, "vpi.in")).read()
+    assert "crystal = T" in txt and "Np = 8" in txt
+    run_pigs_vpi(exe, txt + f"&gpu\n n_walkers = {W}, device = 0\n/\n", str(tmp_path),
+                 extra_files=[os.path.join(src, "config_ini.in")])
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    assert want.shape == (17, 27, 3)
+    assert same_bits(final_worldline(str(tmp_path), want.shape, W)[0], want)
+    for f in FILES:
+        mine = tmp_path / (f if W == 1 else f.replace(".out", ".w0000.out"))
+        assert open(os.path.join(src, f), "rb").read() == open(mine, "rb").read(), f
+    mine = tmp_path / ("perm_vpi.out" if W == 1 else "perm_vpi.w0000.out")
+    assert open(mine).read().split() == open(os.path.join(src, "fort.99")).read().split()
 
 
 def test_worm_sector_with_lstag_beyond_nb_is_refused(exe, tmp_path):
@@ -223,3 +246,26 @@ def test_walkers_sharded_over_contexts_equal_one_context(exe, G, tmp_path):
         assert x.shape == y.shape and x.size > 0, f
         ok = np.isfinite(x)
         assert np.array_equal(ok, np.isfinite(y)) and np.all(np.abs(x - y)[ok] <= 1e-9 * np.abs(x[ok]) + 1e-300), f
+
+
+def test_every_shard_reaches_the_block_all_reduce_exactly_once(exe, tmp_path):
+    """Collective safety of the sharded front end (&gpu n_gpus = G: one host thread + one context per shard, ONE
+    pigs_estimators_allreduce per block and thread, pigs_vpi.f90): every shard must reach the block's all-reduce exactly
+    once whatever happened in its block -- also when none of its walkers had a diagonal step (all of them open for the
+    whole block), where a guard like `if (nd > 0)` around the call would leave the other shards waiting forever on a
+    real RCCL communicator.  CWorm = 30 keeps the worms open most of the time, blocks of 2 steps; the CPU shim counts
+    the calls per context."""
+    base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
+    txt = base.replace("CWorm = 0.5d0", "CWorm = 30.0d0").replace("Nblock = 6", "Nblock = 12").replace("Nstep = 25", "Nstep = 2")
+    assert "CWorm = 30.0d0" in txt and "Nstep = 2" in txt
+    with open(tmp_path / "vpi.in", "w") as f:
+        f.write(txt + "&gpu\n n_walkers = 3, device = 0, n_gpus = 3, same_device = T\n/\n")
+    r = subprocess.run([exe], stdin=open(tmp_path / "vpi.in"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=tmp_path,
+                       timeout=300, env=dict(os.environ, PIGS_SHIM_TRACE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("shim: context rank")]
+    assert len(lines) == 3, r.stderr[-2000:]
+    calls = [int(ln.split(":")[2].split()[0]) for ln in lines]
+    empty = [int(ln.split(",")[1].split()[0]) for ln in lines]
+    assert calls == [12, 12, 12], lines                      # once per block and shard
+    assert sum(empty) > 0, lines                             # ... including blocks in which a shard had no diagonal step
