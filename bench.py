@@ -369,13 +369,20 @@ def main():
         for w in range(W):
             ctx.sampler_seed(w, 1982 + rank * W + w)
         acc0 = ctx.sampler_counters()
-        # warm-up: two whole MC steps from the jittered-lattice start (kernel attributes, first touch, the first sweep's
-        # many rejections), untimed
+        # warm-up: four whole MC steps from the jittered-lattice start (kernel attributes, first touch, the first sweeps'
+        # many rejections) before the timed legs
         ctx.sampler_step(1)
-        ctx.sampler_step(2)
         ctx.sync()
+        # round 2 timed steps 2..4 (one warm-up step): kept as `first_steps` so that the rounds can be compared -- the
+        # walkers are still settling there (fewer accepted head / tail moves, hence fewer bisection levels run) and a
+        # step is ~1 ms cheaper than in the regime the legs below time
+        t0f = time.perf_counter()
+        for q in range(3):
+            ctx.sampler_step(2 + q)
+        ctx.sync()
+        first_steps_s = (time.perf_counter() - t0f) / 3
         nmc = max(1, args.mc_steps)
-        istep = 2
+        istep = 4
 
         def timed_steps(fn):
             """nmc calls of fn, each followed by a stream synchronisation: per-step wall times (s) and their sum.  The
@@ -401,7 +408,7 @@ def main():
             tt = torch.tensor([mc_el], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             mc_el = float(tt.item())
-        acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 2))
+        acc = (ctx.sampler_counters() - acc0).sum(0) / (W * (nmc + 4))
         # the same steps followed by the diagonal-sector estimators of vpi.f90:443-469 (2 x LocalEnergy K4,
         # ThermEnergy K2/K3, g(r) + S(k) K7) for every walker -- ONE library call and one synchronisation per step
         # (pigs_diagonal_estimators): SURVEY 8d's definition of a sweep.  The block's estimator vector (what the front end
@@ -501,7 +508,9 @@ def main():
         mc = {"walker_sweeps_per_s": world * W * nmc / mc_full, "ms_per_mc_step": 1e3 * mc_full / nmc,
               "mc_steps_timed": nmc, "per_step": launch_stats([1e3 * t for t in ts_full]),
               "moves_only": {"walker_sweeps_per_s": world * W * nmc / mc_el, "ms_per_mc_step": 1e3 * mc_el / nmc,
-                             "per_step": launch_stats([1e3 * t for t in ts_moves])},
+                             "per_step": launch_stats([1e3 * t for t in ts_moves]),
+                             "first_steps": {"ms_per_mc_step": 1e3 * first_steps_s, "walker_sweeps_per_s": W / first_steps_s,
+                                             "note": "steps 2-4 after one warm-up step, as round 2 timed them (this rank only)"}},
               "walkers_per_gpu": W, "moves_only_large": mc_large,
               "kernels": "pigs::k_sweep (open/close attempt; bisection + worm moves) around pigs::k_cm (TranslateChain on 2 CUs per "
                          "walker while CUs >= 2 x walkers) + k_local_energy x2, k_slice_energy, "
