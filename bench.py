@@ -316,10 +316,11 @@ def main():
             w, ip, ib, xn, xo = dL[i % 2]
             ctxL.delta_action_batch_dev(nL, w.data_ptr(), ip.data_ptr(), ib.data_ptr(), xn.data_ptr(), xo.data_ptr(),
                                         oL.data_ptr())
-        # warm-up: the context was just created and filled (seconds of host work with an idle GPU): first touch of the
-        # 380 MB, TLB fill and the clock ramp all sit in the first launches -- round 2 timed 6 launches after creation and
-        # saw 72-121 us for the same launch.  40 launches (~4 ms) before anything is timed.
-        for i in range(40):
+        # warm-up: this leg streams from HBM (380 MB, beyond the Infinity Cache) right after seconds of host work with an idle
+        # GPU, and the memory side needs ~100 launches (~10 ms of sustained traffic) to reach its steady state: timed after 40
+        # launches the same 100 launches average 96 us, after 400 or 2 000 they average 77.4 / 76.2 us with p10-p90 of
+        # 75.7-79.6 us (gpurun r3: PIGS_BENCH_LARGE_WARMUP sweep).  Round 2 timed 6 launches after creation and saw 72-121 us.
+        for i in range(int(os.environ.get("PIGS_BENCH_LARGE_WARMUP", "400"))):
             stepL(i)
         ctxL.sync()
         nstepL = max(10, min(args.steps, 100))
@@ -344,7 +345,7 @@ def main():
                  "traffic_source": (TRAFFIC_FILE + " (same PMC passes)") if trafficL is not None else None, "working_set_bytes": int(WL * cfg.M * cfg.dim * cfg.Np * 8),
                  "algorithmic_bytes_per_launch": bytesL, "kernel_ms": msL, "achieved": bytesL / (msL * 1e-3) / 1e9,
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytesL / (msL * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "steps": nstepL, "per_launch": large_launches, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
+                 "steps": nstepL, "warmup_launches": int(os.environ.get("PIGS_BENCH_LARGE_WARMUP", "400")), "per_launch": large_launches, "note": "same kernel and stage as `roofline`, worldlines 3x the 128-walker set: larger "
                                           "than the 256 MiB Infinity Cache, so every slice comes from HBM"}
         try:
             sb, st_s = ctxL.stream_read(30)
