@@ -242,6 +242,15 @@ int pigs_structure_batch(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32
  * (the same kernels), one synchronisation instead of four. */
 int pigs_diagonal_estimators(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t Nbin, double rbin, int32_t Nk,
                              double *en, double *gr, double *Sk);
+/* The same overlapped with the sampler.  _begin snapshots the resident worldlines (a device-to-device copy ordered on the
+ * context's stream: after every step queued so far, before whatever the caller queues next) and starts the estimator
+ * kernels on a second stream of the context, on half of the chip; _end waits for them and returns the results in the
+ * layout of pigs_diagonal_estimators (gr / Sk only if `structure` was non-zero).  Between the two the caller may queue the
+ * next pigs_sampler_step: at 128 walkers per GPU the sampler leaves half of the CUs idle, where a step's estimators
+ * (vpi.f90:443-469) then run for free.  Same kernels on a bit-identical copy: same results.  One pending batch per context. */
+int pigs_diagonal_estimators_begin(pigs_ctx *ctx, int32_t n, const int32_t *walkers, int32_t Nbin, double rbin, int32_t Nk,
+                                   int32_t structure);
+int pigs_diagonal_estimators_end(pigs_ctx *ctx, double *en, double *gr, double *Sk);
 
 /* ---- multi-GPU: block-estimator reduction (new) ------------------------ */
 /* RCCL communicator over `nranks` contexts.  Single-process form (one host thread per

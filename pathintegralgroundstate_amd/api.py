@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "pigs_sampler_init", "pigs_sampler_seed", "pigs_sampler_set_rng", "pigs_sampler_get_rng", "pigs_sampler_step",
     "pigs_sampler_counters", "pigs_sampler_counters16", "pigs_sampler_get_worm", "pigs_sampler_set_worm",
     "pigs_sampler_events", "pigs_sampler_event_ints", "pigs_sampler_nrho", "pigs_slice_download", "pigs_build_tables_kind", "pigs_structure_batch",
-    "pigs_diagonal_estimators",
+    "pigs_diagonal_estimators", "pigs_diagonal_estimators_begin", "pigs_diagonal_estimators_end",
 ]
 
 
@@ -118,6 +118,8 @@ def load_library(path=LIB_PATH):
     L.pigs_slice_download.argtypes = [vp, C.c_int32, _dp]
     L.pigs_structure_batch.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_int32, C.c_double, C.c_int32, _dp, _dp]
     L.pigs_diagonal_estimators.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp]
+    L.pigs_diagonal_estimators_begin.argtypes = [vp, C.c_int32, _ip, C.c_int32, C.c_double, C.c_int32, C.c_int32]
+    L.pigs_diagonal_estimators_end.argtypes = [vp, _dp, _dp, _dp]
     L.pigs_set_tuning.argtypes = [vp, C.c_char_p, C.c_int32]
     L.pigs_selftest_fastmath.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
     L.pigs_selftest_stream_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -456,6 +458,27 @@ class PigsContext:
         _chk(self.L, self.L.pigs_diagonal_estimators(self.h, n, None if w is None else _i(w), int(Nbin), float(rbin), int(Nk),
                                                      _d(en), None if gr is None else _d(gr), None if Sk is None else _d(Sk)),
              "pigs_diagonal_estimators")
+        out = {k: en[:, i] for i, k in enumerate(("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt"))}
+        out["gr"], out["Sk"] = gr, Sk
+        return out
+
+    def diagonal_estimators_begin(self, Nbin=0, rbin=0.0, Nk=0, walkers=None, structure=True):
+        """Asynchronous form: snapshot of the worldlines + estimator kernels on the context's second stream; go on (e.g.
+        with the next sampler_step) and collect with diagonal_estimators_end()."""
+        w = None if walkers is None else _i32(walkers).ravel()
+        n = self.n_walkers if w is None else w.size
+        st = bool(structure and not self.cfg.trap)
+        self._est_pending = (n, int(Nbin), int(Nk), st)
+        _chk(self.L, self.L.pigs_diagonal_estimators_begin(self.h, n, None if w is None else _i(w), int(Nbin), float(rbin),
+                                                           int(Nk), int(st)), "pigs_diagonal_estimators_begin")
+
+    def diagonal_estimators_end(self):
+        n, Nbin, Nk, st = self._est_pending
+        en = np.empty((n, 9))
+        gr = np.empty((n, Nbin)) if st else None
+        Sk = np.empty((n, Nk, self.cfg.dim)) if st else None
+        _chk(self.L, self.L.pigs_diagonal_estimators_end(self.h, _d(en), None if gr is None else _d(gr),
+                                                         None if Sk is None else _d(Sk)), "pigs_diagonal_estimators_end")
         out = {k: en[:, i] for i, k in enumerate(("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt"))}
         out["gr"], out["Sk"] = gr, Sk
         return out

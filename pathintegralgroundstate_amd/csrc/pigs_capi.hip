@@ -133,6 +133,17 @@ struct pigs_ctx {
     unsigned int cm_seq = 1;                // sequence tags of the exchange: advanced by every launch
     bool        counted = false;            // in g_live_ctx
     bool        sampler_ready = false;
+    // asynchronous estimators (pigs_diagonal_estimators_begin / _end): a snapshot of the worldlines and a second stream
+    hipStream_t stream2 = nullptr;
+    hipEvent_t  ev_snap = nullptr;
+    double     *d_shadow = nullptr;
+    DevBuf<int32_t> a_slotw, a_slotb;
+    DevBuf<double>  a_slices, a_res;
+    PinBuf      a_host;                     // results land here (pinned: the copy is truly asynchronous)
+    std::vector<int32_t> a_sw, a_sb;        // slot lists: must outlive the asynchronous upload
+    struct { bool on = false, launched = false; int n = 0, Nbin = 0, Nk = 0; double rbin = 0.0; bool structure = false;
+             size_t ng = 0, nk = 0, nres = 0; } a_pend;
+    hipEvent_t  ev_gate = nullptr;          // recorded behind the TranslateChain kernel of the next step (see launch_pending_estimators)
 };
 
 // live contexts per device of this process: the TranslateChain helpers (pigs_cm.hip) assume that the walkers of ONE
@@ -285,6 +296,11 @@ int pigs_ctx_destroy(pigs_ctx *c)
     if (c->d_VT) (void)hipFree(c->d_VT);
     if (c->d_VTimg) (void)hipFree(c->d_VTimg);
     if (c->d_WF) (void)hipFree(c->d_WF);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_snap) (void)hipEventDestroy(c->ev_snap);
+    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
+    if (c->d_shadow) (void)hipFree(c->d_shadow);
+    c->a_host.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PIGS_OK;
@@ -785,6 +801,8 @@ int pigs_sampler_seed(pigs_ctx *c, int32_t walker, int32_t seed)
     return pigs_sampler_set_rng(c, walker, 624, (const int32_t *)w);
 }
 
+static int launch_pending_estimators(pigs_ctx *c, hipEvent_t gate);
+
 int pigs_sampler_step(pigs_ctx *c, int32_t istep)
 {
     int rc = check_ctx(c); if (rc) return rc;
@@ -830,6 +848,15 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
         c->cm_seq += (unsigned int)c->P.Np + 1;
         sp.do_cm = 0;
         cm_done = true;                                       // (the open / close attempt ran as well)
+        // estimators of the previous step waiting for their turn (pigs_diagonal_estimators_begin): the TranslateChain
+        // kernel fills the chip, the sweep kernel that follows leaves the CUs beyond one per walker idle -- they start there
+        if (c->a_pend.on && !c->a_pend.launched) {
+            HIPCHK(hipEventRecord(c->ev_gate, c->stream));
+            rc = launch_pending_estimators(c, c->ev_gate); if (rc) return rc;
+        }
+    }
+    if (c->a_pend.on && !c->a_pend.launched) {                // a step without the TranslateChain kernel: beside the whole step
+        rc = launch_pending_estimators(c, c->ev_snap); if (rc) return rc;
     }
     const bool need_split = !c->P.trap && !sp.staging && sp.Nlev > 4;
     const bool split = (c->sweep_split || need_split) && diag_supported(c->P, sp);
@@ -1104,6 +1131,110 @@ int pigs_diagonal_estimators(pigs_ctx *c, int32_t n, const int32_t *walkers, int
     if (structure) {
         memcpy(gr, h.data() + 9 * (size_t)n, ng * sizeof(double));
         if (nk) memcpy(Sk, h.data() + 9 * (size_t)n + ng, nk * sizeof(double));
+    }
+    return PIGS_OK;
+}
+
+// ---- the same, overlapped with the sampler ------------------------------------------------------
+// At BASELINE's 128 walkers per GPU the device-resident sampler keeps 128 of the 256 CUs busy for 30 of a step's 38 ms,
+// and the estimators of a step (3.6 ms of kernels and copies on the whole chip) then wait for nothing but the step's
+// worldline.  _begin snapshots the worldlines (one device-to-device copy on the context's stream: 127 MB, ~50 us) and
+// queues the estimator kernels on a SECOND stream of the context, on half the chip; the caller goes on -- typically
+// with the next pigs_sampler_step -- and collects the results with _end.  Same kernels on the same bits as
+// pigs_diagonal_estimators, hence the same results.  One batch can be pending per context.
+// the kernels of the pending batch, on the second stream, once `gate` (an event of the first stream) has passed
+static int launch_pending_estimators(pigs_ctx *c, hipEvent_t gate)
+{
+    if (!c->a_pend.on || c->a_pend.launched) return PIGS_OK;
+    c->a_pend.launched = true;
+    const int n = c->a_pend.n;
+    if (n == 0) return PIGS_OK;
+    const int ns = 2 * c->P.Nb;
+    const size_t nslot = (size_t)n * ns, ng = c->a_pend.ng, nres = c->a_pend.nres;
+    hipStream_t s = c->stream2;
+    HIPCHK(hipStreamWaitEvent(s, gate, 0));
+    HIPCHK(hipMemcpyAsync(c->a_slotw.p, c->a_sw.data(), c->a_sw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->a_slotb.p, c->a_sb.data(), c->a_sb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    double *r = c->a_res.p;
+    const int32_t *dw = c->a_slotw.p + nslot;
+    const int half = c->n_cu / 2 > 0 ? c->n_cu / 2 : 1;
+    HIPCHK(launch_local_energy(c->P, c->d_shadow, c->d_VT, c->d_WF, n, dw, 0, r, s));
+    HIPCHK(launch_local_energy(c->P, c->d_shadow, c->d_VT, c->d_WF, n, dw, 2 * c->P.Nb, r + 3 * (size_t)n, s));
+    HIPCHK(launch_slice_energy(c->P, c->d_shadow, c->d_VT, c->d_VTimg, (int)nslot, c->a_slotw.p, c->a_slotb.p, 1, 1, c->a_slices.p, s, half));
+    HIPCHK(launch_therm_combine(c->P, n, c->a_slices.p, r + 6 * (size_t)n, r + 7 * (size_t)n, r + 8 * (size_t)n, s));
+    if (c->a_pend.structure)
+        HIPCHK(launch_structure(c->P, c->d_shadow, n, dw, c->P.Nb, c->a_pend.Nbin, c->a_pend.rbin, c->a_pend.Nk, r + 9 * (size_t)n,
+                                r + 9 * (size_t)n + ng, s));
+    HIPCHK(hipMemcpyAsync(c->a_host.h, r, nres * sizeof(double), hipMemcpyDeviceToHost, s));
+    return PIGS_OK;
+}
+
+int pigs_diagonal_estimators_begin(pigs_ctx *c, int32_t n, const int32_t *walkers, int32_t Nbin, double rbin, int32_t Nk,
+                                   int32_t structure)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (n < 0) return fail(PIGS_ERR_ARG, "n=%d", n);
+    if (c->a_pend.on) return fail(PIGS_ERR_ARG, "an estimator batch is pending: pigs_diagonal_estimators_end first");
+    rc = check_cm(c); if (rc) return rc;
+    const bool st = structure != 0;
+    if (st && (Nbin < 1 || Nk < 0 || !(rbin > 0.0))) return fail(PIGS_ERR_ARG, "bad structure request");
+    if (st && c->P.trap) return fail(PIGS_ERR_UNSUPPORTED, "structural estimators are defined for PBC runs only (vpi.f90:466)");
+    c->a_pend.n = n; c->a_pend.Nbin = Nbin; c->a_pend.Nk = Nk; c->a_pend.rbin = rbin; c->a_pend.structure = st;
+    c->a_pend.launched = false;
+    if (n == 0) { c->a_pend.on = true; c->a_pend.nres = 0; return PIGS_OK; }
+    const int ns = 2 * c->P.Nb;
+    const size_t nslot = (size_t)n * ns;
+    c->a_sw.resize(nslot + n); c->a_sb.resize(nslot);
+    for (int i = 0; i < n; ++i) {
+        const int w = walkers ? walkers[i] : i;
+        if (w < 0 || w >= c->n_walkers) return fail(PIGS_ERR_ARG, "walker %d out of range", w);
+        for (int b = 0; b < ns; ++b) { c->a_sw[(size_t)i * ns + b] = w; c->a_sb[(size_t)i * ns + b] = b; }
+        c->a_sw[nslot + i] = w;
+    }
+    const size_t ng = st ? (size_t)n * Nbin : 0, nk = st ? (size_t)n * Nk * c->P.dim : 0;
+    const size_t nres = (size_t)9 * n + ng + nk;
+    c->a_pend.ng = ng; c->a_pend.nk = nk; c->a_pend.nres = nres;
+    const size_t nd = c->path_doubles * (size_t)c->n_walkers;
+    if (!c->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_snap, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
+        HIPCHK(hipMalloc((void **)&c->d_shadow, nd * sizeof(double)));
+    }
+    HIPCHK(c->a_slotw.reserve(nslot + n)); HIPCHK(c->a_slotb.reserve(nslot));
+    HIPCHK(c->a_slices.reserve(nslot * 3)); HIPCHK(c->a_res.reserve(nres));
+    HIPCHK(c->a_host.reserve(nres * sizeof(double), 0));
+    // the snapshot is ordered on the context's stream: after everything queued so far, before whatever comes next.  The
+    // kernels themselves are launched by the next pigs_sampler_step behind its TranslateChain kernel (which fills the
+    // chip: estimators started beside it would only take CUs away from it) or, failing that, by _end.
+    HIPCHK(hipMemcpyAsync(c->d_shadow, c->d_paths, nd * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev_snap, c->stream));
+    c->a_pend.on = true;
+    return PIGS_OK;
+}
+
+int pigs_diagonal_estimators_end(pigs_ctx *c, double *en, double *gr, double *Sk)
+{
+    int rc = check_ctx(c); if (rc) return rc;
+    if (!c->a_pend.on) return fail(PIGS_ERR_ARG, "no estimator batch is pending: pigs_diagonal_estimators_begin first");
+    c->a_pend.on = false;
+    const int n = c->a_pend.n;
+    if (n == 0) return PIGS_OK;
+    if (!en || (c->a_pend.structure && (!gr || !Sk))) return fail(PIGS_ERR_ARG, "null output");
+    c->a_pend.on = true;                                  // (launch_pending_estimators looks at it)
+    rc = launch_pending_estimators(c, c->ev_snap);        // no sampler step came in between: start them now
+    c->a_pend.on = false;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    rc = check_cm(c); if (rc) return rc;
+    const double *h = reinterpret_cast<const double *>(c->a_host.h);
+    for (int i = 0; i < n; ++i) {
+        for (int q = 0; q < 3; ++q) { en[9 * i + q] = h[3 * i + q]; en[9 * i + 3 + q] = h[3 * (size_t)n + 3 * i + q]; }
+        en[9 * i + 6] = h[6 * (size_t)n + i]; en[9 * i + 7] = h[7 * (size_t)n + i]; en[9 * i + 8] = h[8 * (size_t)n + i];
+    }
+    if (c->a_pend.structure) {
+        memcpy(gr, h + 9 * (size_t)n, c->a_pend.ng * sizeof(double));
+        if (c->a_pend.nk) memcpy(Sk, h + 9 * (size_t)n + c->a_pend.ng, c->a_pend.nk * sizeof(double));
     }
     return PIGS_OK;
 }

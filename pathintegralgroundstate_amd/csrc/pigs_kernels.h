@@ -33,9 +33,10 @@ hipError_t launch_delta_action(const DevParams &P, int variant, const double *pa
                                const int32_t *ip, const int32_t *ib, const double *xnew,
                                const double *xold, double *out, double *parts, hipStream_t st);
 
+// max_blocks > 0 caps the persistent form's grid (estimators that run NEXT TO the sampler take half the chip)
 hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT, const double *VTimg,
                                int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
-                               int force_mode, int want_spring, double *out, hipStream_t st);
+                               int force_mode, int want_spring, double *out, hipStream_t st, int max_blocks = 0);
 
 hipError_t launch_therm_combine(const DevParams &P, int n, const double *slices, double *E,
                                 double *Ec, double *Ep, hipStream_t st);

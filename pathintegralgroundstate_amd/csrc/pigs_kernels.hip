@@ -492,7 +492,7 @@ static int slice_block(const DevParams &P)
 
 hipError_t launch_slice_energy(const DevParams &P, const double *paths, const double *VT, const double *VTimg,
                                int n_slots, const int32_t *slot_walker, const int32_t *slot_ib,
-                               int force_mode, int want_spring, double *out, hipStream_t st)
+                               int force_mode, int want_spring, double *out, hipStream_t st, int max_blocks)
 {
     if (n_slots <= 0) return hipSuccess;
     // many slices of a periodic system: the persistent LDS-table kernel (one workgroup per CU, 4 slices at a time)
@@ -505,6 +505,7 @@ hipError_t launch_slice_energy(const DevParams &P, const double *paths, const do
         if (!P.trap && VTimg && P.Np <= 256 && !(P.Nmax & 1) && lds <= 160 * 1024 && n_slots >= 8 * ncu) {
             int blocks = (n_slots + 3) / 4;
             if (blocks > ncu) blocks = ncu;
+            if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
             hipError_t e = hipSuccess;
 #define CALLL(D)                                                                                          \
     do {                                                                                                  \

@@ -333,6 +333,26 @@ module pigs_capi
        integer(c_int) :: rc
      end function pigs_diagonal_estimators
 
+     ! the same overlapped with the next step of the device-resident sampler: _begin snapshots the worldlines and queues the
+     ! estimator kernels on the context's second stream, _end collects (layouts as pigs_diagonal_estimators)
+     function pigs_diagonal_estimators_begin(ctx,n,walkers,Nbin,rbin,Nk,structure) &
+          & bind(C,name='pigs_diagonal_estimators_begin') result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value             :: ctx
+       integer(c_int32_t), value      :: n,Nbin,Nk,structure
+       integer(c_int32_t), intent(in) :: walkers(*)
+       real(c_double), value          :: rbin
+       integer(c_int) :: rc
+     end function pigs_diagonal_estimators_begin
+
+     function pigs_diagonal_estimators_end(ctx,en,gr,Sk) bind(C,name='pigs_diagonal_estimators_end') result(rc)
+       import :: c_int, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       real(c_double)     :: en(9,*)
+       type(c_ptr), value :: gr,Sk
+       integer(c_int) :: rc
+     end function pigs_diagonal_estimators_end
+
      function pigs_sampler_event_ints(ctx,n) bind(C,name='pigs_sampler_event_ints') result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: ctx

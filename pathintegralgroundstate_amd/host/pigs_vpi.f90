@@ -236,6 +236,9 @@ contains
   type(pigs_sweep_params) :: swp_par
   real(8), allocatable, target :: gr_inc(:,:),sk_inc(:,:,:)
   real(8), allocatable :: en9(:,:)
+  logical :: est_pending,est_have,pend_struct
+  integer :: pend_nd
+  integer, allocatable :: pend_list(:)
   integer(c_int64_t), allocatable :: dev_acc(:,:),dev_acc0(:,:)
   integer(c_int32_t), allocatable :: dev_open(:),dev_iworm(:),dev_ev(:,:),dev_reset(:)
   real(8), allocatable :: dev_nrho(:,:,:)
@@ -341,7 +344,8 @@ contains
   end do
 
   allocate (ipv(NW),iupd(NW),partner(NW),diag_list(NW),act(NW),isopen0(NW),swp(NW),wl(NW))
-  allocate (E1(NW),E2(NW),K1(NW),P1(NW),Et(NW),Kt(NW),Pt(NW),en9(9,NW))
+  allocate (E1(NW),E2(NW),K1(NW),P1(NW),Et(NW),Kt(NW),Pt(NW),en9(9,NW),pend_list(NW))
+  est_pending = .false.; est_have = .false.; pend_struct = .false.; pend_nd = 0
   allocate (acc_cm(NW),acc_bd(NW),acc_head(NW),acc_tail(NW),acc_cm_half(NW),acc_bd_half(NW))
   allocate (acc_head_half(NW),acc_tail_half(NW),acc_open(NW),acc_close(NW),acc_swap(NW))
   allocate (try_open(NW),try_close(NW),try_swap(NW),try_cm(NW),try_stag(NW),try_cm_half(NW),try_stag_half(NW))
@@ -385,11 +389,58 @@ contains
      idiag_block = 0; ngr = 0; gr = 0.d0; Sk = 0.d0
      BE = 0.d0; BE2 = 0.d0; BT = 0.d0; BT2 = 0.d0
 
-     do istep=1,Nstep
+     ! one trip more than steps: the estimators of a step are collected at the top of the NEXT trip -- with the
+     ! device-resident sampler they run on the context's second stream, on a snapshot of the worldlines, while that next step
+     ! is sampled (pigs_diagonal_estimators_begin / _end: at 128 walkers per GPU the sampler leaves half of the CUs idle)
+     do istep=1,Nstep+1
+
+        if (device_sampler .and. istep<=Nstep) then
+           ! the whole step of every walker in one launch (K6); queued, not waited for
+           call pigs_check(pigs_sampler_step(ctx,int(istep,c_int32_t)),'pigs_sampler_step')
+        end if
+        ! ---- the previous step's estimators (reference vpi.f90:443-473)
+        if (est_pending) then
+           if (pend_struct) then
+              call pigs_check(pigs_diagonal_estimators_end(ctx,en9,c_loc(gr_inc),c_loc(sk_inc)),'pigs_diagonal_estimators_end')
+           else
+              call pigs_check(pigs_diagonal_estimators_end(ctx,en9,c_null_ptr,c_null_ptr),'pigs_diagonal_estimators_end')
+           end if
+           est_pending = .false.
+           est_have = .true.
+        end if
+        if (est_have) then
+           est_have = .false.
+           do i=1,pend_nd
+              E1(i) = en9(1,i); E2(i) = en9(4,i); Et(i) = en9(7,i); Kt(i) = en9(8,i); Pt(i) = en9(9,i)
+           end do
+           !$omp parallel do schedule(dynamic,1) private(w,E,Pot,Kin) num_threads(min(pend_nd,16))
+           do i=1,pend_nd
+              w = pend_list(i)
+              idiag(w) = idiag(w)+1; idiag_aux(w) = idiag_aux(w)+1; idiag_block(w) = idiag_block(w)+1
+              E   = 0.5d0*(E1(i)+E2(i))
+              Pot = Pt(i)
+              Kin = E-Pot
+              BE(:,w)  = BE(:,w)+[E,Kin,Pot]
+              BT(:,w)  = BT(:,w)+[Et(i),Kt(i),Pot]
+              BE2(:,w) = BE2(:,w)+[E**2,Kin**2,Pot**2]
+              BT2(:,w) = BT2(:,w)+[Et(i)**2,Kt(i)**2,Pot**2]
+              ngr(w) = ngr(w)+1
+              if (.not. trap) then
+                 if (device_sampler) then
+                    gr(:,w)   = gr(:,w)+gr_inc(:,i)
+                    Sk(:,:,w) = Sk(:,:,w)+sk_inc(:,:,i)
+                 else
+                    ! (host-driven sampler: the mirror still holds the step's worldline -- the next step's moves come below)
+                    call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
+                    call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
+                 end if
+              end if
+           end do
+           !$omp end parallel do
+        end if
+        if (istep>Nstep) exit
 
         if (device_sampler) then
-           ! the whole step of every walker in one launch (K6)
-           call pigs_check(pigs_sampler_step(ctx,int(istep,c_int32_t)),'pigs_sampler_step')
            if (CWorm>0.d0) then
               ! sector of every walker after the step and what its worm did during it: the permutation-cycle
               ! bookkeeping of the reference (sample_mod.f90:530-594) is replayed from the event log
@@ -513,42 +564,22 @@ contains
            end if
         end do
         if (nd>0) then
-           ! one call, one synchronisation: LocalEnergy x2 (K4), ThermEnergy (K2/K3) and -- device-resident sampler, PBC --
-           ! g(r), S(k) on the device (K7); the host-driven sampler keeps the structural estimators on its mirror
-           if (device_sampler .and. .not. trap) then
-              call pigs_check(pigs_diagonal_estimators(ctx,int(nd,c_int32_t),wl,int(Nbin,c_int32_t),rbin,int(Nk,c_int32_t), &
-                   & en9,c_loc(gr_inc),c_loc(sk_inc)),'pigs_diagonal_estimators')
+           ! LocalEnergy x2 (K4), ThermEnergy (K2/K3) and -- device-resident sampler, PBC -- g(r), S(k) on the device (K7) in
+           ! one library call; the host-driven sampler keeps the structural estimators on its mirror.  Accumulated at the top
+           ! of the next trip.
+           pend_nd = nd
+           pend_list(1:nd) = diag_list(1:nd)
+           if (device_sampler) then
+              pend_struct = .not. trap
+              call pigs_check(pigs_diagonal_estimators_begin(ctx,int(nd,c_int32_t),wl,int(Nbin,c_int32_t),rbin, &
+                   & int(Nk,c_int32_t),merge(1_c_int32_t,0_c_int32_t,pend_struct)),'pigs_diagonal_estimators_begin')
+              est_pending = .true.
            else
-              if (.not. device_sampler) call sampler_flush(s)
+              call sampler_flush(s)
               call pigs_check(pigs_diagonal_estimators(ctx,int(nd,c_int32_t),wl,0_c_int32_t,0.d0,0_c_int32_t, &
                    & en9,c_null_ptr,c_null_ptr),'pigs_diagonal_estimators')
+              est_have = .true.
            end if
-           do i=1,nd
-              E1(i) = en9(1,i); E2(i) = en9(4,i); Et(i) = en9(7,i); Kt(i) = en9(8,i); Pt(i) = en9(9,i)
-           end do
-           !$omp parallel do schedule(dynamic,1) private(w,E,Pot,Kin) num_threads(min(nd,16))
-           do i=1,nd
-              w = diag_list(i)
-              idiag(w) = idiag(w)+1; idiag_aux(w) = idiag_aux(w)+1; idiag_block(w) = idiag_block(w)+1
-              E   = 0.5d0*(E1(i)+E2(i))
-              Pot = Pt(i)
-              Kin = E-Pot
-              BE(:,w)  = BE(:,w)+[E,Kin,Pot]
-              BT(:,w)  = BT(:,w)+[Et(i),Kt(i),Pot]
-              BE2(:,w) = BE2(:,w)+[E**2,Kin**2,Pot**2]
-              BT2(:,w) = BT2(:,w)+[Et(i)**2,Kt(i)**2,Pot**2]
-              ngr(w) = ngr(w)+1
-              if (.not. trap) then
-                 if (device_sampler) then
-                    gr(:,w)   = gr(:,w)+gr_inc(:,i)
-                    Sk(:,:,w) = Sk(:,:,w)+sk_inc(:,:,i)
-                 else
-                    call pair_correlation(ep,s%Path(:,:,Nb,w),gr(:,w))
-                    call structure_factor(ep,s%Path(:,:,Nb,w),Sk(:,:,w))
-                 end if
-              end if
-           end do
-           !$omp end parallel do
         end if
 
      end do   ! istep

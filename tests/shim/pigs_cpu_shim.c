@@ -28,6 +28,7 @@ struct pigs_ctx {
     int     grank;
     long    n_allreduce;   /* calls of pigs_estimators_allreduce on this context (PIGS_SHIM_TRACE) */
     long    n_allreduce_nd0; /* ... of which with vec[0] == 0: a block in which this shard had no diagonal step */
+    double *pend_en, *pend_gr, *pend_sk; int pend_n, pend_nb, pend_nk, pend_st;   /* pigs_diagonal_estimators_begin / _end */
 };
 
 static char g_err[256] = "";
@@ -66,6 +67,7 @@ int pigs_ctx_destroy(pigs_ctx *c)
     if (getenv("PIGS_SHIM_TRACE"))
         fprintf(stderr, "shim: context rank %d: %ld all-reduce calls, %ld with no diagonal step in the shard\n", c->grank,
                 c->n_allreduce, c->n_allreduce_nd0);
+    free(c->pend_en); free(c->pend_gr); free(c->pend_sk);
     free(c->VT); free(c->WF); free(c->paths); free(c);
     return PIGS_OK;
 }
@@ -303,5 +305,25 @@ int pigs_diagonal_estimators(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t 
         pigs_therm_energy_batch(c, 1, &w, &en[9 * i + 6], &en[9 * i + 7], &en[9 * i + 8]);
     }
     if (gr && Sk) return pigs_structure_batch(c, n, ws, c->s.Nb, Nbin, rbin, Nk, gr, Sk);
+    return PIGS_OK;
+}
+
+/* asynchronous pair: the shim evaluates at _begin (a snapshot in the literal sense) and hands the results out at _end */
+int pigs_diagonal_estimators_begin(pigs_ctx *c, int32_t n, const int32_t *ws, int32_t Nbin, double rbin, int32_t Nk, int32_t structure)
+{
+    free(c->pend_en); free(c->pend_gr); free(c->pend_sk);
+    c->pend_n = n; c->pend_nb = Nbin; c->pend_nk = Nk; c->pend_st = structure;
+    c->pend_en = (double *)malloc(sizeof(double) * 9 * (size_t)(n > 0 ? n : 1));
+    c->pend_gr = structure ? (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (Nbin > 0 ? Nbin : 1)) : NULL;
+    c->pend_sk = structure ? (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (Nk > 0 ? Nk : 1) * c->s.dim) : NULL;
+    return pigs_diagonal_estimators(c, n, ws, Nbin, rbin, Nk, c->pend_en, c->pend_gr, c->pend_sk);
+}
+int pigs_diagonal_estimators_end(pigs_ctx *c, double *en, double *gr, double *Sk)
+{
+    memcpy(en, c->pend_en, sizeof(double) * 9 * (size_t)c->pend_n);
+    if (c->pend_st && gr && Sk) {
+        memcpy(gr, c->pend_gr, sizeof(double) * (size_t)c->pend_n * c->pend_nb);
+        memcpy(Sk, c->pend_sk, sizeof(double) * (size_t)c->pend_n * c->pend_nk * c->s.dim);
+    }
     return PIGS_OK;
 }

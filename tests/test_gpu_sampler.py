@@ -434,3 +434,61 @@ def test_diagonal_estimators_one_call_equals_the_separate_calls(gpu_lib, oracle)
             for k, v in zip(("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt"), list(a) + list(b) + list(t)):
                 assert same_bits(one[k], v), k
             assert same_bits(one["gr"], gr) and same_bits(one["Sk"], Sk)
+
+
+def test_overlapped_estimators_see_the_snapshot_not_the_next_step(gpu_lib, oracle):
+    """pigs_diagonal_estimators_begin / _end: the estimators of step n run on the context's second stream on a SNAPSHOT of
+    the worldlines while step n+1 is sampled on the first.  Their results must be those of the synchronous call made
+    between the two steps, bit for bit (same kernels, bit-identical copy), for several steps in a row and for a subset of
+    the walkers; a second _begin without _end and an _end without _begin are refused."""
+    from oracle.pyoracle import System
+    cfg = SystemConfig(dim=3, Np=48, Nb=16, density=0.3, dt=5e-3, Rm=1.2, Nlev=4, Nstag=2, Lstag=8, CMFreq=1, delta_cm=0.3)
+    S = System(dim=3, Np=48, Nb=16, density=0.3, dt=5e-3, Rm=1.2)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W = 4
+
+    def fresh():
+        ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W)
+        ctx.sampler_init()
+        Paths = []
+        for w in range(W):
+            P, g = oracle.init_path(S, 300 + w)
+            Paths.append(P)
+            ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+        ctx.upload_all(np.stack(Paths))
+        return ctx
+    keys = ("E1", "K1", "V1", "E2", "K2", "V2", "Et", "Kt", "Vt", "gr", "Sk")
+    # reference: step, synchronous estimators, step, ...
+    a = fresh()
+    want = []
+    for istep in range(1, 6):
+        a.sampler_step(istep)
+        want.append(a.diagonal_estimators(30, cfg.rcut / 30, 5))
+    wa = a.download_all()
+    a.close()
+    # overlapped: step n+1 is queued BEFORE the estimators of step n are collected
+    b = fresh()
+    got = []
+    b.sampler_step(1)
+    for istep in range(2, 7):
+        b.diagonal_estimators_begin(30, cfg.rcut / 30, 5)
+        with pytest.raises(gpu_lib.PigsError, match="pending"):
+            b.diagonal_estimators_begin(30, cfg.rcut / 30, 5)
+        if istep <= 5:
+            b.sampler_step(istep)
+        got.append(b.diagonal_estimators_end())
+    with pytest.raises(gpu_lib.PigsError, match="pending"):
+        b.diagonal_estimators_end()
+    assert same_bits(b.download_all(), wa)
+    for n, (g, w_) in enumerate(zip(got, want)):
+        for k in keys:
+            assert same_bits(g[k], w_[k]), (n, k)
+    # a subset, without the structural estimators
+    sub = np.array([2, 0], np.int32)
+    ref = b.diagonal_estimators(walkers=sub, structure=False)
+    b.diagonal_estimators_begin(walkers=sub, structure=False)
+    r = b.diagonal_estimators_end()
+    for k in keys[:9]:
+        assert same_bits(r[k], ref[k]), k
+    assert r["gr"] is None
+    b.close()
