@@ -136,10 +136,16 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
         if (mine && pn < P.Np) nxv = Pw[(size_t)(b0 + eb) * sl + (size_t)ek * P.NpPad + pn];
         // Delta S of this range's beads: bead r*NW + (wid + r) mod NW in round r (a plain stride would give a wave only
         // odd or only even beads, and odd beads -- force terms -- cost 1.3x the even ones)
+        // The range that holds the chain's LAST bead takes it FIRST: an end bead gathers the trial function's table from
+        // global memory and costs a lone wave twice an inner bead (7 100 against 3 500 cycles), and with 81 (161) beads
+        // on 16 waves it used to be the one bead of the last, otherwise empty round.  Which wave evaluates a bead when
+        // changes no bit: every Delta S lands in dS[bead] and the sum runs in bead order.
+        const bool last_first = b1 == M && nbo > 1;
         for (int r = 0; r * NW < nbo; ++r) {
             int i = wid + r;
             i = r * NW + (i >= NW ? i % NW : i);
             if (i >= nbo) continue;
+            if (last_first) i = i == 0 ? nbo - 1 : i - 1;             // local order: nbo-1, 0, 1, ..., nbo-2
             double a[DIM], c[DIM];
 #pragma unroll
             for (int k = 0; k < DIM; ++k) { c[k] = pc[i * DIM + k]; a[k] = wrap_coord(P, false, k, c[k] + dx[k]); }
