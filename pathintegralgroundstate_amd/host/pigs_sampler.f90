@@ -56,6 +56,11 @@ module pigs_sampler
      real(c_double), allocatable :: it_wgt(:)
      ! ---- beads to write to the device before the next evaluation
      integer :: n_commit = 0, ccap = 0
+     ! pigs_commit_staged is asynchronous and its kernel reads the pinned arrays below IN PLACE: after a flush they may not
+     ! be written until a synchronising call has passed (round 3: a Swap stage in which no walker got as far as a proposal
+     ! flushed and returned without one, the next mover's select_half overwrote slot 1 while the kernel was still on its
+     ! way, and one accepted bead never reached the device -- found by scripts/k6_vs_host_soak.py, ~1 in 100 MC steps)
+     logical :: commit_in_flight = .false.
      integer(c_int32_t), pointer :: cm_w(:) => null(), cm_ip(:) => null(), cm_ib(:) => null()
      real(c_double), pointer     :: cm_x(:,:) => null()
      ! ---- per-walker bookkeeping of the move in flight
@@ -87,7 +92,7 @@ contains
     s%dt = dt; s%density = density; s%CWorm = CWorm; s%ctx = ctx
     s%pi = acos(-1.d0)
     s%nthr = host_threads(W)
-    s%n_items = 0; s%cap = 0; s%n_commit = 0; s%ccap = 0
+    s%n_items = 0; s%cap = 0; s%n_commit = 0; s%ccap = 0; s%commit_in_flight = .false.
     s%n_eval_items = 0; s%n_eval_calls = 0; s%t_eval = 0.d0
     do k=1,dim
        s%Lbox(k) = Lbox(k)
@@ -136,6 +141,7 @@ contains
     type(sampler_t), intent(inout) :: s
     call pigs_check(pigs_path_upload_all(s%ctx,s%Path),'pigs_path_upload_all')
     s%n_commit = 0
+    s%commit_in_flight = .false.
   end subroutine sampler_upload
 
   ! write every pending accepted bead to the device now (otherwise done lazily before the next
@@ -145,6 +151,7 @@ contains
     call flush_commits(s)
     ! the staged commit is asynchronous: make sure it has consumed its arrays before they are reused
     call pigs_check(pigs_sync(s%ctx),'pigs_sync')
+    s%commit_in_flight = .false.
   end subroutine sampler_flush
 
   subroutine grow_items(s,n)
@@ -271,6 +278,10 @@ contains
     integer, intent(in) :: w,ip,ib
     real(8), intent(in) :: x(s%dim)
     integer :: n
+    if (s%commit_in_flight) then                 ! the previous flush may still be reading the staging arrays
+       call pigs_check(pigs_sync(s%ctx),'pigs_sync')
+       s%commit_in_flight = .false.
+    end if
     if (s%n_commit+1>s%ccap) call grow_commit(s,s%n_commit+1)
     n = s%n_commit+1
     s%cm_w(n) = w-1; s%cm_ip(n) = ip; s%cm_ib(n) = ib; s%cm_x(:,n) = x
@@ -292,6 +303,7 @@ contains
     if (s%n_commit==0) return
     call pigs_check(pigs_commit_staged(s%ctx,int(s%n_commit,c_int64_t)),'pigs_commit_staged')
     s%n_commit = 0
+    s%commit_in_flight = .true.
   end subroutine flush_commits
 
   subroutine begin_stage(s)
@@ -310,6 +322,7 @@ contains
     if (s%n_items==0) return
     call system_clock(c0,rate)
     call pigs_check(pigs_delta_action_staged(s%ctx,int(s%n_items,c_int64_t)),'pigs_delta_action_staged')
+    s%commit_in_flight = .false.                 ! (synchronous: the commit kernel ahead of it in the stream is done)
     call system_clock(c1)
     s%t_eval = s%t_eval+dble(c1-c0)/dble(rate)
     s%n_eval_items = s%n_eval_items+s%n_items

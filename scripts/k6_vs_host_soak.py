@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Soak: the device-resident sampler against the host-driven one (host libm, bit-identical to the reference wherever a
+fixture exists) through the front end, same input, many steps: final worldlines must be identical bit for bit, the
+permutation and OBDM files byte for byte.  Exercises the device log (pigs_log_host.h) on ~1e7 Box-Muller radii drawn by
+real trajectories.   usage (GPU box): python scripts/k6_vs_host_soak.py [Nstep_total]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pathintegralgroundstate_amd", "host", "pigs_vpi")
+nstep = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+CASES = [("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.4d0"),
+         ("sta", "dim = 2, Np = 21, density = 0.1d0", "Nb = 12, Lstag = 6, Nlev = 2", "0.5d0"),
+         ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.0d0")]
+if os.environ.get("CASE"):
+    CASES = [CASES[int(os.environ["CASE"])]]
+ok = True
+for sampling, system, samp, cworm in CASES:
+    inp = f"""&system
+ {system}, trap = F
+/
+&samp
+ resume = F, dt = 1.0d-2, {samp}, seed = 4242, delta_cm = 0.2d0, CMFreq = 2,
+ sampling = '{sampling}', Nstag = 2, Nblock = {max(1, nstep // 100)}, Nstep = 100, Nbin = 50, Nk = 10
+/
+&obdm
+ swapping = T, Nobdm = 3, Npw = 1, CWorm = {cworm}
+/
+&wavefun
+ Nmax = 4000, wf_table = T, v_table = T
+/
+&jastrow
+ Rm = 1.10d0
+/
+&extpot
+ a_ho = 1.0d0
+/
+"""
+    res = {}
+    for dev in "FT":
+        d = tempfile.mkdtemp()
+        with open(os.path.join(d, "vpi.in"), "w") as f:
+            f.write(inp + f"&gpu\n n_walkers = 4, device = 0, device_sampler = {dev}, checkpointing = F\n/\n")
+        t0 = time.time()
+        with open(os.path.join(d, "vpi.in")) as fin, open(os.path.join(d, "out.txt"), "w") as fo:
+            r = subprocess.run([EXE], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=d, timeout=1500)
+        assert r.returncode == 0, open(os.path.join(d, "out.txt")).read()[-2000:]
+        res[dev] = (d, time.time() - t0)
+    a, b = res["F"][0], res["T"][0]
+    wa, wb = np.fromfile(os.path.join(a, "worldlines_final.bin")), np.fromfile(os.path.join(b, "worldlines_final.bin"))
+    same = np.array_equal(wa.view(np.uint64), wb.view(np.uint64))
+    files = all(open(os.path.join(a, f"{n}.w{w:04d}.out"), "rb").read() == open(os.path.join(b, f"{n}.w{w:04d}.out"), "rb").read()
+                for w in range(4) for n in ("nr_vpi", "perm_vpi"))
+    if not same:                     # where: first block whose 64-bit energies differ, per walker (blocks of 100 steps)
+        for w in range(4):
+            la = open(os.path.join(a, f"e_vpi.w{w:04d}.hex")).read().splitlines()
+            lb = open(os.path.join(b, f"e_vpi.w{w:04d}.hex")).read().splitlines()
+            first = next((i for i, (x, y) in enumerate(zip(la, lb)) if x != y), None)
+            print(f"   walker {w}: first differing diagonal block line {first} of {len(la)}/{len(lb)}: "
+                  f"{la[first].split()[0] if first is not None else '-'}", flush=True)
+    print(f"{sampling}: {nstep} MC steps x 4 walkers: worldlines bit-identical = {same}, OBDM / permutation files identical = {files}"
+          f"  (host-driven {res['F'][1]:.1f} s, device {res['T'][1]:.1f} s)", flush=True)
+    ok = ok and same and files
+sys.exit(0 if ok else 1)
