@@ -14,38 +14,53 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "pathintegralgroundstate_amd", "host", "pigs_vpi")
 nstep = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-CASES = [("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.4d0"),
-         ("sta", "dim = 2, Np = 21, density = 0.1d0", "Nb = 12, Lstag = 6, Nlev = 2", "0.5d0"),
-         ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.0d0")]
+# (sampling, &system fields, &samp fields, CWorm [+ obdm fields], extra: dict(dt, wavefun, extpot, gpu))
+CASES = [("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.4d0", {}),
+         ("sta", "dim = 2, Np = 21, density = 0.1d0", "Nb = 12, Lstag = 6, Nlev = 2", "0.5d0", {}),
+         ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.0d0", {}),
+         # 1D harmonic trap, N = 2, staging movers + worm + swap (BASELINE config 1's shape; quirk Q9: swapping = T)
+         ("sta", "dim = 1, Np = 2, density = 0.1d0, trap = T", "Nb = 10, Lstag = 6, Nlev = 2", "0.3d0", {"extpot": "a_ho = 1.0d0"}),
+         # 2D trap, bisection, diagonal sector only
+         ("bis", "dim = 2, Np = 6, density = 0.1d0, trap = T", "Nb = 8, Lstag = 4, Nlev = 2", "0.0d0", {"extpot": "a_ho = 1.0d0 1.3d0"}),
+         # the reference's default: analytic trial function (wf_table = F)
+         ("bis", "dim = 3, Np = 16, density = 0.365d0", "Nb = 8, Lstag = 8, Nlev = 3", "0.5d0", {"wavefun": "Nmax = 10000, wf_table = F, v_table = T"}),
+         # five bisection levels: the stage-machine kernel (pigs_diag.hip)
+         ("bis", "dim = 3, Np = 20, density = 0.3d0", "Nb = 20, Lstag = 8, Nlev = 5", "0.4d0", {}),
+         # three 64-partner passes per bead, two partial waves, more OBDM iterations
+         ("bis", "dim = 3, Np = 130, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 4", "0.4d0, Npw = 2, Nobdm = 5", {"steps": 0.25}),
+         ("bis", "dim = 2, Np = 37, density = 0.06d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0", {}),
+         # walkers sharded over two contexts on this one GPU (one host thread each, one all-reduce per block)
+         ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 3", "0.4d0", {"gpu": "n_gpus = 2, same_device = T, "})]
 if os.environ.get("CASE"):
-    CASES = [CASES[int(os.environ["CASE"])]]
+    CASES = [CASES[int(x)] for x in os.environ["CASE"].split(",")]
 ok = True
-for sampling, system, samp, cworm in CASES:
+for sampling, system, samp, cworm, extra in CASES:
+    nst = max(100, int(nstep * extra.get("steps", 1.0)) // 100 * 100)
     inp = f"""&system
- {system}, trap = F
+ {system}{"" if "trap" in system else ", trap = F"}
 /
 &samp
  resume = F, dt = 1.0d-2, {samp}, seed = 4242, delta_cm = 0.2d0, CMFreq = 2,
- sampling = '{sampling}', Nstag = 2, Nblock = {max(1, nstep // 100)}, Nstep = 100, Nbin = 50, Nk = 10
+ sampling = '{sampling}', Nstag = 2, Nblock = {nst // 100}, Nstep = 100, Nbin = 50, Nk = 10
 /
 &obdm
- swapping = T, Nobdm = 3, Npw = 1, CWorm = {cworm}
+ swapping = T, {"" if "Nobdm" in cworm else "Nobdm = 3, "}{"" if "Npw" in cworm else "Npw = 1, "}CWorm = {cworm}
 /
 &wavefun
- Nmax = 4000, wf_table = T, v_table = T
+ {extra.get("wavefun", "Nmax = 4000, wf_table = T, v_table = T")}
 /
 &jastrow
  Rm = 1.10d0
 /
 &extpot
- a_ho = 1.0d0
+ {extra.get("extpot", "a_ho = 1.0d0")}
 /
 """
     res = {}
     for dev in "FT":
         d = tempfile.mkdtemp()
         with open(os.path.join(d, "vpi.in"), "w") as f:
-            f.write(inp + f"&gpu\n n_walkers = 4, device = 0, device_sampler = {dev}, checkpointing = F\n/\n")
+            f.write(inp + f"&gpu\n {extra.get('gpu', '')}n_walkers = 4, device = 0, device_sampler = {dev}, checkpointing = F\n/\n")
         t0 = time.time()
         with open(os.path.join(d, "vpi.in")) as fin, open(os.path.join(d, "out.txt"), "w") as fo:
             r = subprocess.run([EXE], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=d, timeout=1500)
@@ -55,7 +70,7 @@ for sampling, system, samp, cworm in CASES:
     wa, wb = np.fromfile(os.path.join(a, "worldlines_final.bin")), np.fromfile(os.path.join(b, "worldlines_final.bin"))
     same = np.array_equal(wa.view(np.uint64), wb.view(np.uint64))
     files = all(open(os.path.join(a, f"{n}.w{w:04d}.out"), "rb").read() == open(os.path.join(b, f"{n}.w{w:04d}.out"), "rb").read()
-                for w in range(4) for n in ("nr_vpi", "perm_vpi"))
+                for w in range(4) for n in ("nr_vpi", "perm_vpi") if os.path.exists(os.path.join(a, f"{n}.w{w:04d}.out")))
     if not same:                     # where: first block whose 64-bit energies differ, per walker (blocks of 100 steps)
         for w in range(4):
             la = open(os.path.join(a, f"e_vpi.w{w:04d}.hex")).read().splitlines()
@@ -63,7 +78,7 @@ for sampling, system, samp, cworm in CASES:
             first = next((i for i, (x, y) in enumerate(zip(la, lb)) if x != y), None)
             print(f"   walker {w}: first differing diagonal block line {first} of {len(la)}/{len(lb)}: "
                   f"{la[first].split()[0] if first is not None else '-'}", flush=True)
-    print(f"{sampling}: {nstep} MC steps x 4 walkers: worldlines bit-identical = {same}, OBDM / permutation files identical = {files}"
+    print(f"{sampling} [{system}; {samp}; CWorm = {cworm}{'; ' + str(extra) if extra else ''}]: {nst} MC steps x 4 walkers: worldlines bit-identical = {same}, OBDM / permutation files identical = {files}"
           f"  (host-driven {res['F'][1]:.1f} s, device {res['T'][1]:.1f} s)", flush=True)
     ok = ok and same and files
 sys.exit(0 if ok else 1)
