@@ -6,14 +6,15 @@
 ! Reads the reference's six namelists from standard input (system, samp, obdm, wavefun,
 ! extpot, jastrow -- same names, same defaults, reference vpi_mod.f90:14-80,
 ! system_mod.f90:15-34) plus one optional group of its own,
-!     &gpu  n_walkers = 1, device = 0, n_gpus = 1, device_sampler = F, potential = 'aziz2', k1_variant = 0  /
+!     &gpu  n_walkers = 1, device = 0, n_gpus = 1, [device_sampler = T|F,] potential = 'aziz2', k1_variant = 0  /
 ! (n_gpus = G: the walkers are sharded in contiguous blocks over G GPUs -- devices device .. device+G-1, one
 ! context and one OpenMP host thread per GPU, no exchange while sampling -- and the block estimators of the shards
 ! meet ONCE per block in one all-reduce (RCCL over xGMI: pigs_comm_init_all / pigs_estimators_allreduce); thread 0
 ! writes the walker-summed files.  same_device = T puts every shard on `device`: a one-GPU rehearsal.)
 ! (potential: aziz2 | lj | dipolar -- the reference selects it by editing system_mod.f90)
-! (device_sampler = T: the whole MC step runs on the GPU, kernel K6 -- diagonal sector with
-! sampling='bis' and CWorm = 0 only; otherwise the host-driven lock-step sampler is used)
+! (device_sampler = T: the whole MC step of every walker runs on the GPU in one launch, kernel K6 -- every mover of
+! the reference; F: the host-driven lock-step sampler, one K1 batch per move stage.  Left out: K6 wherever it serves
+! the input, the host-driven sampler otherwise.  The two give the same files and the same worldlines, bit for bit.)
 ! runs n_walkers independent PIGS chains in lock-step (walker w uses seed+w-1, so walker 1
 ! IS the reference's chain), every Delta S / energy sum on the GPU through libpigs_hip.so,
 ! and writes the reference's observable files: e_vpi.out, et_vpi.out ('(5g20.10e3)'),
@@ -42,6 +43,9 @@ program pigs_vpi
   integer           :: dim,Np,Nb,seed,CMFreq,Lstag,Nlev,Nstag,Nblock,Nstep,Nbin,Nk
   integer           :: Nobdm,Npw,Nmax,n_walkers,device,ios,k1_variant,n_gpus
   logical           :: device_sampler,checkpointing,same_device
+  logical           :: sampler_auto
+  integer(c_int)    :: rc_probe
+  type(pigs_sweep_params) :: probe_par
   character (len=8) :: potential
   integer           :: pot_kind
   namelist /system/  dim,Np,density,crystal,trap
@@ -82,7 +86,14 @@ program pigs_vpi
      read (5,nml=extpot,iostat=ios); rewind (5)
   end if
   read (5,nml=jastrow,iostat=ios); rewind (5)
+  ! device_sampler left out of &gpu = automatic: the device-resident sampler (K6) wherever it serves the input, the
+  ! host-driven one otherwise.  Whether it was given is found by reading the group twice with opposite defaults.
+  device_sampler = .true.
   read (5,nml=gpu,iostat=ios);     rewind (5)
+  sampler_auto = device_sampler
+  device_sampler = .false.
+  read (5,nml=gpu,iostat=ios);     rewind (5)
+  sampler_auto = sampler_auto .neqv. device_sampler
 
   if (.not. v_table) then
      write (0,*) 'pigs_vpi: v_table = T is required (the reference Force() is a stub: system_mod.f90:186-209)'
@@ -161,6 +172,13 @@ program pigs_vpi
           & 'pigs_set_tuning')
   end do
   if (G>1) call pigs_check(pigs_comm_init_all(ctxs,int(G,c_int32_t)),'pigs_comm_init_all')
+  if (sampler_auto) then
+     ! both samplers give the same files and the same worldlines, bit for bit (soaked against each other and against the
+     ! reference's arithmetic: profiles/r03_k6_vs_host_soak.txt); the device-resident one is ~30 times faster at N = 256
+     call fill_sweep_params(probe_par)
+     rc_probe = pigs_sampler_init(ctxs(1),probe_par)
+     device_sampler = rc_probe==PIGS_OK
+  end if
   allocate (chk_all(dim,Np,0:2*Nb,NWtot),AE_all(3,NWtot),AT_all(3,NWtot),diag_bl_all(NWtot))
   diag_bl_all = 0
 
@@ -175,6 +193,13 @@ program pigs_vpi
   print '(a,g13.6)', '  > Time step           :',dt
   print '(a,i6)',    '  > Number of blocks    :',Nblock
   print '(a,i6)',    '  > MC steps per block  :',Nstep
+  if (device_sampler) then
+     print '(a)',    '  > Sampler             : device-resident (K6: one launch per MC step)'
+  else if (sampler_auto) then
+     print '(a)',    '  > Sampler             : host-driven (the device-resident sampler does not serve this input or backend)'
+  else
+     print '(a)',    '  > Sampler             : host-driven (lock-step batches through K1)'
+  end if
 
   !=====================================================================
 
@@ -196,6 +221,17 @@ program pigs_vpi
   end do
 
 contains
+
+  ! namelists samp + obdm as the library's sweep parameters
+  subroutine fill_sweep_params(p)
+    type(pigs_sweep_params), intent(out) :: p
+    p%Nlev = Nlev; p%Nstag = Nstag; p%CMFreq = CMFreq; p%Lstag = Lstag
+    p%delta_cm = delta_cm
+    p%CWorm = CWorm; p%density = density; p%rbin = rbin
+    p%sampling = merge(1,0,sampling=="sta")
+    p%swapping = merge(1,0,swapping); p%Nobdm = Nobdm; p%Nbin = Nbin; p%Npw = Npw
+    p%reserved = 0
+  end subroutine fill_sweep_params
 
   !---------------------------------------------------------------------
   ! one shard: the walkers lo(ish)..hi(ish) on context ctxs(ish), the reference's block / step structure
@@ -319,11 +355,7 @@ contains
   end do
   call sampler_upload(s)
   if (device_sampler) then
-     swp_par%Nlev = Nlev; swp_par%Nstag = Nstag; swp_par%CMFreq = CMFreq; swp_par%Lstag = Lstag
-     swp_par%delta_cm = delta_cm
-     swp_par%CWorm = CWorm; swp_par%density = density; swp_par%rbin = rbin
-     swp_par%sampling = merge(1,0,sampling=="sta")
-     swp_par%swapping = merge(1,0,swapping); swp_par%Nobdm = Nobdm; swp_par%Nbin = Nbin; swp_par%Npw = Npw
+     call fill_sweep_params(swp_par)
      call pigs_check(pigs_sampler_init(ctx,swp_par),'pigs_sampler_init')
      call pigs_check(pigs_sampler_event_ints(ctx,rpos),'pigs_sampler_event_ints')
      allocate (dev_open(NW),dev_iworm(NW),dev_ev(rpos,NW),dev_nrho(0:Npw,Nbin,NW),dev_reset(NW))

@@ -76,7 +76,7 @@ def _lbox(src):
                                   "he4_wormbusy_s8", "he4_wf_analytic"])
 def test_gpu_front_end_matches_reference_program(exe, name, tmp_path):
     src = os.path.join(RUNS, name)
-    _run(exe, open(os.path.join(src, "vpi.in")).read(), str(tmp_path))
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n device_sampler = F\n/\n", str(tmp_path))     # the host-driven sampler
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
     assert same_bits(got, want), "trajectory diverged from the reference (a decision flipped)"
@@ -92,7 +92,7 @@ def test_gpu_front_end_exact_term_kernel(exe, tmp_path):
     """&gpu k1_variant = 2: the Delta-S kernel that keeps the reference's rounding of every term gives the same
     trajectory (bit-identical final worldline) as the default short arithmetic and the reference program."""
     src = os.path.join(RUNS, "he4_worm_s1982")
-    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, k1_variant = 2\n/\n", str(tmp_path))
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = F, k1_variant = 2\n/\n", str(tmp_path))
     want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
     assert same_bits(got, want)
@@ -108,7 +108,7 @@ def test_gpu_front_end_at_baseline_sizes(exe, name, tmp_path):
     drv = dict(np.load(os.path.join(src, "driver.npz")))
     pot = str(drv["potential"])
     _run(exe, open(os.path.join(src, "vpi.in")).read() +
-         f"&gpu\n n_walkers = 1, device = 0, potential = '{pot}', checkpointing = F\n/\n", str(tmp_path))
+         f"&gpu\n n_walkers = 1, device = 0, device_sampler = F, potential = '{pot}', checkpointing = F\n/\n", str(tmp_path))
     shape = tuple(int(x) for x in drv["Path_shape"])
     got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(shape)
     check_worldline_vs_driver(got, drv, None, tol=0.0)
@@ -144,7 +144,7 @@ def test_gpu_front_end_device_sampler_at_baseline_sizes(exe, name, tmp_path):
 
 def test_gpu_lockstep_walkers(exe, tmp_path):
     base = open(os.path.join(RUNS, "he4_worm_s1982", "vpi.in")).read()
-    _run(exe, base + "&gpu\n n_walkers = 3, device = 0\n/\n", str(tmp_path))
+    _run(exe, base + "&gpu\n n_walkers = 3, device = 0, device_sampler = F\n/\n", str(tmp_path))
     got = np.fromfile(tmp_path / "worldlines_final.bin")
     for w, seed in enumerate((1982, 1983, 1984)):
         src = os.path.join(RUNS, f"he4_worm_s{seed}")
@@ -468,3 +468,39 @@ def test_samplers_agree_bit_for_bit_over_hundreds_of_steps(exe, tmp_path, sampli
             assert np.all(er <= 1e-10) and np.all(em <= MIXED_TOL), w
     out = open(a / "stdout.txt").read()
     assert "Swap acc" in out
+
+
+def test_sampler_choice_is_automatic_when_left_out(exe, tmp_path):
+    """&gpu without device_sampler: the front end takes the device-resident sampler where it serves the input (and says so)
+    -- same files as the reference run -- and the host-driven one where it does not (a trapped system with Nlev = 5: K6's
+    trap form stops at four levels)."""
+    src = os.path.join(RUNS, "he4_worm_s1982")
+    a = tmp_path / "auto"; a.mkdir()
+    _run(exe, open(os.path.join(src, "vpi.in")).read(), str(a))
+    assert "device-resident (K6" in open(a / "stdout.txt").read()
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    assert same_bits(np.fromfile(a / "worldlines_final.bin").reshape(want.shape), want)
+    assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(a / "nr_vpi.out", "rb").read()
+    b = tmp_path / "fallback"; b.mkdir()
+    inp = """&system
+ dim = 2, Np = 6, density = 0.1d0, trap = T
+/
+&samp
+ resume = F, dt = 1.0d-2, Nb = 20, seed = 11, delta_cm = 0.2d0, CMFreq = 1, sampling = 'bis', Lstag = 4, Nlev = 5, Nstag = 2,
+ Nblock = 1, Nstep = 5, Nbin = 50, Nk = 10
+/
+&obdm
+ swapping = T, CWorm = 0.0d0, Nobdm = 0, Npw = 0
+/
+&wavefun
+ Nmax = 4000, wf_table = T, v_table = T
+/
+&jastrow
+ Rm = 1.10d0
+/
+&extpot
+ a_ho = 1.0d0 1.3d0
+/
+"""
+    _run(exe, inp, str(b))
+    assert "host-driven (the device-resident sampler does not serve" in open(b / "stdout.txt").read()

@@ -92,7 +92,9 @@ def test_device_sampler_matches_host_sampler_counters(gpu_lib, oracle):
     cfg = _cfg(name)
     blocks, final, counters = _run_device(gpu_lib, oracle, cfg, [cfg.seed], cfg.Nblock, cfg.Nstep)
     with tempfile.TemporaryDirectory() as td:
-        with open(os.path.join(RUNS, name, "vpi.in")) as fin, open(os.path.join(td, "out.txt"), "w") as fo:
+        with open(os.path.join(td, "vpi.in"), "w") as f:
+            f.write(open(os.path.join(RUNS, name, "vpi.in")).read() + "&gpu\n device_sampler = F\n/\n")      # the host-driven sampler
+        with open(os.path.join(td, "vpi.in")) as fin, open(os.path.join(td, "out.txt"), "w") as fo:
             subprocess.run([os.path.join(host, "pigs_vpi")], stdin=fin, stdout=fo, cwd=td, check=True, timeout=600)
         got = np.fromfile(os.path.join(td, "worldlines_final.bin")).reshape(final[0].shape)
     assert same_bits(final[0], got)
