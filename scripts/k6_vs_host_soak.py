@@ -39,6 +39,9 @@ BIG = [("bis", "dim = 3, Np = 256, density = 0.365d0", "Nb = 80, Lstag = 32, Nle
         {"big": 1, "walkers": 2, "dt": "5.0d-3", "gpu": "potential = 'dipolar', "})]
 # more walkers than CUs: the sweep kernel's 4-wave form (three workgroups per CU), TranslateChain with one workgroup per walker
 BIG.append(("bis", "dim = 3, Np = 16, density = 0.3d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0", {"walkers": 300, "steps": 0.1}))
+# 64 lock-step walkers with busy worms (large staged batches and commit lists), staging and bisection sampling
+BIG.append(("sta", "dim = 3, Np = 24, density = 0.3d0", "Nb = 14, Lstag = 8, Nlev = 3", "0.6d0", {"walkers": 64, "steps": 0.5}))
+BIG.append(("bis", "dim = 3, Np = 24, density = 0.3d0", "Nb = 16, Lstag = 8, Nlev = 4", "0.6d0, Nobdm = 6", {"walkers": 64, "steps": 0.5}))
 if os.environ.get("CASE"):
     CASES = CASES + BIG
     CASES = [CASES[int(x)] for x in os.environ["CASE"].split(",")]
