@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse "
                                                       "the multi-process path on a one-GPU machine)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE-config-5 sampler leg")
     ap.add_argument("--no-mc", action="store_true", help="skip the device-resident sampler legs (profiling runs of K1 only)")
     ap.add_argument("--mc-steps", type=int, default=14, help="MC steps per timed leg of the device-resident sampler (>= 0.5 s at 128 walkers)")
     ap.add_argument("--mc-large-walkers", type=int, default=1024, help="walkers of the second sampler leg (0: skip)")
@@ -507,6 +508,46 @@ def main():
                             "per_step": launch_stats([1e3 * t for t in ts2]), "note": "moves only; four walkers per CU"}
             finally:
                 ctx2.close()
+        # BASELINE config 5's shape on this GPU: N=256, 321 beads, dipolar r^-3 table, worm sector with the stock CWorm = 0.5,
+        # Nobdm = 10, swapping, two partial waves -- divergent worm control flow next to the long-tail pair kernel.  Moves only.
+        mc_c5 = None
+        if world == 1 and not args.no_c5:
+            c5 = SystemConfig(dim=3, Np=args.np, Nb=2 * args.nb, density=0.365, dt=5e-3, Rm=1.2, Nlev=4, Nstag=5, Lstag=32,
+                              CMFreq=1, delta_cm=0.12)
+            VT5, WF5 = api.build_tables(c5, "dipolar")
+            ctx5 = api.PigsContext(c5, VT5, WF5, n_walkers=W, device_id=local)
+            try:
+                P5, _ = make_workload(c5, min(W, 32), 1, seed=555)
+                P5 = np.concatenate([P5] * ((W + len(P5) - 1) // len(P5)))[:W]
+                ctx5.upload_all(P5)
+                ctx5.sampler_init(Nlev=4, Nstag=5, CMFreq=1, Lstag=32, delta_cm=c5.delta_cm_eff, CWorm=0.5, swapping=True,
+                                  Nobdm=10, Nbin=100, Npw=2)
+                ctx5.set_tuning("cm_exclusive", 1)             # the main context is idle during this leg
+                xe5 = np.repeat(P5[:, c5.Nb, c5.Np - 1][:, None, :], 2, axis=1)
+                ctx5.sampler_set_worm(np.zeros(W, np.int32), np.zeros(W, np.int32), xe5)
+                del P5
+                for w in range(W):
+                    ctx5.sampler_seed(w, 9000 + w)
+                for q in range(6):                              # worms open during the warm-up
+                    ctx5.sampler_step(1 + q)
+                ctx5.sync()
+                k0 = ctx5.sampler_counters16().sum(0)
+                n5 = max(2, min(8, nmc))
+                ts5 = []
+                for q in range(n5):
+                    t = time.perf_counter()
+                    ctx5.sampler_step(7 + q)
+                    ctx5.sync()
+                    ts5.append(time.perf_counter() - t)
+                k1 = ctx5.sampler_counters16().sum(0) - k0
+                mc_c5 = {"workload": "N=%d, %d beads, dipolar table, CWorm=0.5 Nobdm=10 Npw=2 swapping, %d walkers" % (c5.Np, c5.M, W),
+                         "walker_sweeps_per_s": W * n5 / sum(ts5), "ms_per_mc_step": 1e3 * sum(ts5) / n5,
+                         "per_step": launch_stats([1e3 * t for t in ts5]),
+                         "open_walkers_now": int(ctx5.sampler_get_worm()[0].sum()),
+                         "worm_events_in_timed_steps": {"open": "%d/%d" % (k1[5], k1[4]), "close": "%d/%d" % (k1[7], k1[6]),
+                                                        "swap": "%d/%d" % (k1[13], k1[12])}}
+            finally:
+                ctx5.close()
         # K2 alone (ThermEnergy of every walker: 2Nb slices x Np(Np-1)/2 pairs each) against the FP64 vector peak
         ctx.therm_energy_batch()
         t3 = time.perf_counter()
@@ -526,7 +567,7 @@ def main():
                              "per_step": launch_stats([1e3 * t for t in ts_moves]),
                              "first_steps": {"ms_per_mc_step": 1e3 * first_steps_s, "walker_sweeps_per_s": W / first_steps_s,
                                              "note": "steps 2-4 after one warm-up step, as round 2 timed them (this rank only)"}},
-              "walkers_per_gpu": W, "moves_only_large": mc_large,
+              "walkers_per_gpu": W, "moves_only_large": mc_large, "config5": mc_c5,
               "kernels": "pigs::k_sweep (open/close attempt; bisection + worm moves) around pigs::k_cm (TranslateChain on 2 CUs per "
                          "walker while CUs >= 2 x walkers) + k_local_energy x2, k_slice_energy, "
                          "k_therm_combine, k_structure per step",

@@ -90,7 +90,10 @@ int pigs_stream(pigs_ctx *ctx, void **hip_stream);
  *      on H, bit for bit).  -1 (default): H = min(4, CUs / walkers), at least 1 (one workgroup per walker exchanges
  *      nothing and is still the faster TranslateChain); 0: inside the sweep kernel; 1..4: at most that many.  H > 1 only
  *      while the context is the process's only one on its device; a cooperating workgroup that waits in vain (several
- *      PROCESSES crowding one chip: set 1 there) gives up after seconds and the next pigs_sync returns PIGS_ERR_HIP. */
+ *      PROCESSES crowding one chip: set 1 there) gives up after seconds and the next pigs_sync returns PIGS_ERR_HIP.
+ *   "cm_exclusive": 1 = the caller vouches that the process's other contexts on this device are idle while this one
+ *      samples, so H > 1 stays allowed although it is not the only live context (bench.py's extra legs).
+ *   "cm_fault": TEST ONLY -- forces the time-out of that exchange once. */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()
  * on blocks*256*iters random operands; bad[0..3] = mismatch counts (sqrt, n/r, r/dr, n/dr). */

@@ -128,6 +128,7 @@ struct pigs_ctx {
     int         n_cu = 256;
     // TranslateChain by several workgroups per walker (pigs_cm.hip): -1 as many as fit (default), 0 off, H >= 1 at most H
     int         cm_split = -1;
+    bool        cm_exclusive = false;       // the caller vouches that no other context's kernels run on this device meanwhile
     unsigned long long *d_xch = nullptr;    // exchange buffer of the cooperating workgroups
     int        *h_cm_err = nullptr;         // (pinned, device-visible) set by a workgroup whose partner never answered
     unsigned int cm_seq = 1;                // sequence tags of the exchange: advanced by every launch
@@ -359,6 +360,10 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
     }
     if (!strcmp(key, "cm_fault")) {             // TEST ONLY: force the time-out path of the TranslateChain exchange (pigs_cm.hip)
         c->sweep.cm_fault = value != 0;
+        return PIGS_OK;
+    }
+    if (!strcmp(key, "cm_exclusive")) {         // 1: other contexts of this process on the device are idle while this one samples
+        c->cm_exclusive = value != 0;           // (bench.py's extra legs next to its main context): cooperating workgroups allowed
         return PIGS_OK;
     }
     if (!strcmp(key, "sweep_threads")) {
@@ -826,7 +831,11 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
         // cooperating workgroups wait for each other: only while this context has the chip to itself.  One workgroup per
         // walker (H = 1) exchanges nothing and is still the faster TranslateChain (sixteen waves on the LDS table image:
         // 46.8 -> 44.8 ms per MC step at 256 walkers, 95 -> 74 ms at 512, where the sweep kernel runs its 4-wave form)
-        if (H > 1 && g_live_ctx[c->device & 63].load() != 1) H = 1;
+        if (H > 1 && g_live_ctx[c->device & 63].load() != 1 && !c->cm_exclusive) H = 1;
+        // a lowered H means longer bead ranges per workgroup: 321 beads fit two workgroups per walker but not one (rows, LDS)
+        // -- then TranslateChain stays inside the sweep kernel (round 3: the BASELINE-config-5 leg of bench.py next to a
+        // second live context, and the sharded front end on one GPU, failed here with "invalid argument")
+        if (H >= 1 && !cm_fits(c->P, H)) H = 0;
     }
     bool cm_done = false;
     if (H >= 1) {

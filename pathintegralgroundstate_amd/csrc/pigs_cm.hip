@@ -247,6 +247,10 @@ int cm_helpers(const DevParams &P, const SweepParams &sp, int n_cu)
     return H;
 }
 
+// does the kernel fit with exactly H workgroups per walker?  (Fewer workgroups = longer ranges: H = 2 can fit where H = 1 does
+// not -- 321 beads: 966 rows and 165 KB of LDS on one workgroup -- so a caller that lowers H re-checks.)
+bool cm_fits(const DevParams &P, int H) { return H >= 1 && H <= 4 && cm_threads(P, H) != 0; }
+
 size_t cm_exchange_words(const DevParams &P) { return (size_t)P.nW * 2 * P.M * 2; }
 
 hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned int seq0, double *paths, const double *VTimg,

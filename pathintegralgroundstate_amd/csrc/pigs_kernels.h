@@ -82,6 +82,7 @@ hipError_t launch_diag(const DevParams &P, const SweepParams &sp, int threads, d
                        const double *WF, uint32_t *rng, unsigned long long *counters, const double *worm, hipStream_t st);
 // pigs_cm.hip: the TranslateChain moves of a periodic system by H cooperating workgroups per walker
 int cm_helpers(const DevParams &P, const SweepParams &sp, int n_cu);        // H the chip and the kernel allow (0: none)
+bool cm_fits(const DevParams &P, int H);                                    // the kernel fits with exactly H workgroups per walker
 size_t cm_exchange_words(const DevParams &P);                               // 64-bit words of the exchange buffer
 hipError_t launch_cm(const DevParams &P, const SweepParams &sp, int H, unsigned int seq0, double *paths, const double *VTimg,
                      const double *WF, uint32_t *rng, unsigned long long *counters, const double *worm,

@@ -494,3 +494,32 @@ def test_overlapped_estimators_see_the_snapshot_not_the_next_step(gpu_lib, oracl
         assert same_bits(r[k], ref[k]), k
     assert r["gr"] is None
     b.close()
+
+
+def test_translate_chain_kernel_steps_aside_when_the_chain_does_not_fit_one_workgroup(gpu_lib, oracle):
+    """pigs_cm.hip holds a workgroup's bead range in LDS with a thread per coordinate: 321 beads fit two workgroups per
+    walker but not one (966 rows, 165 KB).  When H is lowered to 1 -- cm_split = 1, or a second live context on the device
+    (the sharded front end on one GPU, bench.py's extra legs) -- TranslateChain must stay inside the sweep kernel instead of
+    failing the step with 'invalid argument' (round 3).  Same trajectory as cm_split = 0 and as two workgroups per walker."""
+    from oracle.pyoracle import System
+    cfg = SystemConfig(dim=3, Np=12, Nb=160, density=0.3, dt=5e-3, Rm=1.2, Nlev=4, Nstag=1, Lstag=8, CMFreq=1, delta_cm=0.3)
+    S = System(dim=3, Np=12, Nb=160, density=0.3, dt=5e-3, Rm=1.2)
+    VT, WF = gpu_lib.build_tables(cfg)
+    res = {}
+    for cm in (0, 1, 2):
+        ctx = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=2)
+        ctx.sampler_init()
+        ctx.set_tuning("cm_split", cm)
+        Paths = []
+        for w in range(2):
+            P, g = oracle.init_path(S, 60 + w)
+            Paths.append(P)
+            ctx.sampler_set_rng(w, g.mti, np.array(g.mt[:], np.uint32))
+        ctx.upload_all(np.stack(Paths))
+        for istep in range(1, 4):
+            ctx.sampler_step(istep)
+        res[cm] = (ctx.download_all(), ctx.sampler_counters16())
+        ctx.close()
+    assert res[0][1][:, 14].min() > 0
+    for cm in (1, 2):
+        assert same_bits(res[cm][0], res[0][0]) and np.array_equal(res[cm][1], res[0][1]), cm
