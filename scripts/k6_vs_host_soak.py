@@ -42,6 +42,11 @@ BIG.append(("bis", "dim = 3, Np = 16, density = 0.3d0", "Nb = 12, Lstag = 6, Nle
 # 64 lock-step walkers with busy worms (large staged batches and commit lists), staging and bisection sampling
 BIG.append(("sta", "dim = 3, Np = 24, density = 0.3d0", "Nb = 14, Lstag = 8, Nlev = 3", "0.6d0", {"walkers": 64, "steps": 0.5}))
 BIG.append(("bis", "dim = 3, Np = 24, density = 0.3d0", "Nb = 16, Lstag = 8, Nlev = 4", "0.6d0, Nobdm = 6", {"walkers": 64, "steps": 0.5}))
+# one dimension with periodic boundaries; a 3D trap with bisection sampling and a busy worm; no TranslateChain at all (CMFreq
+# beyond the run) and every-step OBDM with no swaps (swapping = F needs CWorm = 0 in the reference: quirk Q9 -- so CWorm = 0 here)
+BIG.append(("bis", "dim = 1, Np = 9, density = 0.5d0", "Nb = 12, Lstag = 6, Nlev = 3", "0.4d0", {}))
+BIG.append(("bis", "dim = 3, Np = 7, density = 0.1d0, trap = T", "Nb = 8, Lstag = 6, Nlev = 3", "0.5d0", {"extpot": "a_ho = 1.0d0 1.2d0 0.9d0"}))
+BIG.append(("sta", "dim = 3, Np = 20, density = 0.3d0", "Nb = 32, Lstag = 32, Nlev = 3", "0.5d0, Nobdm = 12", {"steps": 0.5}))
 if os.environ.get("CASE"):
     CASES = CASES + BIG
     CASES = [CASES[int(x)] for x in os.environ["CASE"].split(",")]
