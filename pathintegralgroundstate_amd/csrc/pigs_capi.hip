@@ -359,7 +359,7 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
         return PIGS_OK;
     }
     if (!strcmp(key, "cm_fault")) {             // TEST ONLY: force the time-out path of the TranslateChain exchange (pigs_cm.hip)
-        c->sweep.cm_fault = value != 0;
+        c->sweep.cm_fault = (c->sweep.cm_fault & ~1) | (value != 0 ? 1 : 0);
         return PIGS_OK;
     }
     if (!strcmp(key, "cm_exclusive")) {         // 1: other contexts of this process on the device are idle while this one samples

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(NT, 1) void k_cm(
             // there only after the others published the move in between, i.e. after they finished reading this one
             const unsigned int tag = seq0 + n_try;
             unsigned long long *X = xch + ((size_t)w * 2 + (n_try & 1)) * (size_t)M * 2;
-            const int spin_limit = sp.cm_fault ? 2048 : kCmSpinLimit;
-            if (tid < nbo && !(sp.cm_fault && h == H - 1)) {          // (cm_fault: this range's values never arrive)
+            const int spin_limit = (sp.cm_fault & 1) ? 2048 : kCmSpinLimit;
+            if (tid < nbo && !((sp.cm_fault & 1) && h == H - 1)) {          // (cm_fault: this range's values never arrive)
                 const unsigned long long v = (unsigned long long)__double_as_longlong(dS[b0 + tid]);
                 const unsigned long long hi = (unsigned long long)tag << 32;
                 __hip_atomic_store(&X[(size_t)(b0 + tid) * 2],     hi | (v & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
