@@ -712,7 +712,8 @@ int pigs_sampler_init(pigs_ctx *c, const pigs_sweep_params *sp)
     // Nlev: any 2^Nlev <= 2 Nb up to 7 levels for periodic systems (pigs_diag.hip beyond 4), 4 for trapped ones;
     // Lstag <= Nb is a requirement of the worm's half-chain moves only (vpi_mod.f90:1376-1817): with CWorm = 0 any
     // Lstag <= 2 Nb works, as in the reference
-    if ((!sta && (sp->Nlev < 1 || sp->Nlev > (c->P.trap ? 4 : 7) || (1 << sp->Nlev) > 2 * c->P.Nb)) || sp->Nstag < 0 || sp->CMFreq < 1 ||
+    // (head / tail moves bisect 2^nl beads with nl = 2 .. max(Nlev, 2): vpi_mod.f90:1023)
+    if ((!sta && (sp->Nlev < 1 || sp->Nlev > (c->P.trap ? 4 : 7) || (1 << (sp->Nlev > 2 ? sp->Nlev : 2)) > 2 * c->P.Nb)) || sp->Nstag < 0 || sp->CMFreq < 1 ||
         sp->Lstag < 2 || sp->Lstag > (worm0 ? c->P.Nb : 2 * c->P.Nb))
         return fail(PIGS_ERR_ARG, "sweep params out of range (Nlev=%d Nstag=%d CMFreq=%d Lstag=%d)", sp->Nlev, sp->Nstag, sp->CMFreq, sp->Lstag);
     const bool worm = sp->CWorm > 0.0;

@@ -559,7 +559,9 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
 
 bool diag_supported(const DevParams &P, const SweepParams &sp)
 {
-    return !P.trap && !sp.staging && !(P.Nmax & 1) && sp.Nlev >= 1 && sp.Nlev <= 7 && (1 << sp.Nlev) <= 2 * P.Nb &&
+    // (Nlev >= 2: with Nlev = 1 the head / tail moves still bisect 2^2 beads -- vpi_mod.f90:1023 -- and this kernel sizes its
+    // buffers by 2^Nlev; the one-launch kernel serves that case)
+    return !P.trap && !sp.staging && !(P.Nmax & 1) && sp.Nlev >= 2 && sp.Nlev <= 7 && (1 << sp.Nlev) <= 2 * P.Nb &&
            diag_form(P, sp, 1024) != 0;
 }
 

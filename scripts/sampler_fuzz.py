@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Fuzz of the samplers through the front end: random inputs (dimension, particles, beads, 'bis' / 'sta', Lstag, Nlev, Nstag, CMFreq,
+CWorm, Nobdm, Npw, trap, analytic or tabulated trial function, dt, walkers, shards) run three times -- host-driven sampler on the GPU,
+device-resident sampler, and the CPU twin (host sampler over the scalar oracle = the reference's arithmetic) -- and compared bit for bit
+(final worldlines; OBDM and permutation files byte for byte).   usage (GPU box): python scripts/sampler_fuzz.py [n_cases] [seed]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pathintegralgroundstate_amd", "host", "pigs_vpi")
+SHIM_EXE = os.path.join(ROOT, "tests", "shim", "_build", "pigs_vpi")
+ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
+bad = 0
+t0 = time.time()
+for case in range(ncase):
+    dim = int(rng.integers(1, 4))
+    trap = bool(rng.random() < 0.3)
+    Np = int(rng.choice([2, 3, 5, 9, 16, 21, 33, 64, 70])) if not trap else int(rng.choice([2, 3, 6, 9]))
+    Nb = int(rng.choice([4, 6, 8, 10, 12, 16, 20, 33]))
+    sampling = "bis" if rng.random() < 0.6 else "sta"
+    cworm = float(rng.choice([0.0, 0.3, 0.6, 2.0]))
+    nlev_max = min(4 if trap else 6, int(np.floor(np.log2(2 * Nb))))
+    Nlev = int(rng.integers(1, nlev_max + 1))
+    Lstag = int(rng.integers(2, (Nb if cworm > 0 else 2 * Nb) + 1))
+    Nstag = int(rng.integers(1, 4))
+    CMFreq = int(rng.integers(1, 4))
+    Nobdm = int(rng.integers(0, 6))
+    Npw = int(rng.integers(0, 3))
+    wf_table = "T" if rng.random() < 0.75 else "F"
+    dt = float(rng.choice([5e-3, 1e-2, 3e-2]))
+    dens = float(rng.choice([0.05, 0.2, 0.365]))
+    NW = int(rng.choice([1, 2, 5]))
+    G = 2 if (NW >= 2 and rng.random() < 0.3) else 1
+    a_ho = " ".join(["1.0d0", "1.3d0", "0.8d0"][:dim])
+    nstep = 40
+    inp = f"""&system
+ dim = {dim}, Np = {Np}, density = {dens}d0, trap = {'T' if trap else 'F'}
+/
+&samp
+ resume = F, dt = {dt}d0, Nb = {Nb}, seed = {1000 + case}, delta_cm = 0.2d0, CMFreq = {CMFreq},
+ sampling = '{sampling}', Lstag = {Lstag}, Nlev = {Nlev}, Nstag = {Nstag}, Nblock = 2, Nstep = {nstep // 2}, Nbin = 40, Nk = 6
+/
+&obdm
+ swapping = T, Nobdm = {Nobdm}, Npw = {Npw}, CWorm = {cworm}d0
+/
+&wavefun
+ Nmax = 4000, wf_table = {wf_table}, v_table = T
+/
+&jastrow
+ Rm = 1.10d0
+/
+&extpot
+ a_ho = {a_ho}
+/
+"""
+    tag = (f"case {case}: dim={dim} Np={Np} Nb={Nb} {sampling} Lstag={Lstag} Nlev={Nlev} Nstag={Nstag} CMFreq={CMFreq} CWorm={cworm} "
+           f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G}")
+    out = {}
+    fail = None
+    for arm in "FTC":
+        d = tempfile.mkdtemp()
+        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = {'T' if arm == 'T' else 'F'}, checkpointing = F"
+        if G > 1:
+            gpu += f", n_gpus = {G}, same_device = T"
+        with open(os.path.join(d, "vpi.in"), "w") as f:
+            f.write(inp + gpu + "\n/\n")
+        with open(os.path.join(d, "vpi.in")) as fin, open(os.path.join(d, "out.txt"), "w") as fo:
+            r = subprocess.run([SHIM_EXE if arm == "C" else EXE], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=d, timeout=900)
+        if r.returncode != 0:
+            fail = f"arm {arm} rc={r.returncode}: " + open(os.path.join(d, "out.txt")).read()[-300:].replace("\n", " | ")
+            break
+        out[arm] = d
+    if fail is None:
+        w = {a: np.fromfile(os.path.join(out[a], "worldlines_final.bin")) for a in out}
+        if not (np.array_equal(w["F"].view(np.uint64), w["T"].view(np.uint64))):
+            fail = "host-driven (GPU) vs device-resident: worldlines differ"
+        elif not np.array_equal(w["F"].view(np.uint64), w["C"].view(np.uint64)):
+            fail = "GPU vs CPU twin: worldlines differ"
+        else:
+            for wk in range(NW):
+                for nme in ("nr_vpi", "perm_vpi"):
+                    fn = f"{nme}.w{wk:04d}.out" if NW > 1 else f"{nme}.out"
+                    pa, pb = os.path.join(out["F"], fn), os.path.join(out["T"], fn)
+                    if os.path.exists(pa) and open(pa, "rb").read() != open(pb, "rb").read():
+                        fail = f"{fn} differs between the samplers"
+    if fail:
+        bad += 1
+        print("FAIL", tag, "|", fail, flush=True)
+    elif case % 5 == 0:
+        print("ok  ", tag, flush=True)
+print(f"{ncase} cases, {bad} failing, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)

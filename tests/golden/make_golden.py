@@ -231,6 +231,10 @@ RUNS = {
     # wf_table = F, the reference's default: the McMillan trial function evaluated analytically (system_mod.f90:38-66)
     "he4_wf_analytic": dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=8, Nlev=3, Nstag=3,
                             Nblock=4, Nstep=20, CWorm="0.5d0", Nobdm=4, Npw=1, wf_table="F"),
+    # Nlev = 1, the reference's DEFAULT (vpi_mod.f90:47): the head / tail moves still bisect 2^2 beads (`Nlev' = int((level-1)*grnd())+2`,
+    # vpi_mod.f90:1023,1209), only Bisection itself works on 2^1.  Round 3's sampler fuzz found K6 clamping nl to Nlev there.
+    "he4_nlev1": dict(dim=3, Np=16, Nb=8, seed=1982, sampling="bis", Lstag=6, Nlev=1, Nstag=3,
+                      Nblock=4, Nstep=15, CWorm="3.0d0", Nobdm=3, Npw=1, dt="2.0d-2"),
     # ---- BASELINE sizes ------------------------------------------------------------------------
     # C3: liquid 4He N=256, 161 beads, stock schedule, CWorm = 0
     "c3_n256_s1982": dict(dim=3, Np=256, Nb=80, seed=1982, sampling="bis", Lstag=32, Nlev=4, Nstag=5,

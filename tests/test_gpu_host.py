@@ -73,7 +73,7 @@ def _lbox(src):
 
 
 @pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0", "he4_wormbusy_s7",
-                                  "he4_wormbusy_s8", "he4_wf_analytic"])
+                                  "he4_wormbusy_s8", "he4_wf_analytic", "he4_nlev1"])
 def test_gpu_front_end_matches_reference_program(exe, name, tmp_path):
     src = os.path.join(RUNS, name)
     _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n device_sampler = F\n/\n", str(tmp_path))     # the host-driven sampler
@@ -504,3 +504,19 @@ def test_sampler_choice_is_automatic_when_left_out(exe, tmp_path):
 """
     _run(exe, inp, str(b))
     assert "host-driven (the device-resident sampler does not serve" in open(b / "stdout.txt").read()
+
+
+def test_gpu_device_sampler_with_the_references_default_nlev_1(exe, tmp_path):
+    """Nlev = 1 is the reference's DEFAULT (vpi_mod.f90:47).  Its head / tail moves draw their level as int((Nlev-1)*grnd())+2
+    = 2 and bisect 2^2 beads all the same (vpi_mod.f90:1023,1209); only Bisection itself works on 2^1.  Round 3's sampler
+    fuzz (scripts/sampler_fuzz.py) found the device-resident sampler clamping that level to Nlev: every Nlev = 1 input took
+    another trajectory than the host-driven sampler.  Here against the reference PROGRAM (he4_nlev1: open, close, half-chain
+    moves): worldline bit-identical, OBDM and permutation files identical, 64-bit block energies 1e-10."""
+    src = os.path.join(RUNS, "he4_nlev1")
+    _run(exe, open(os.path.join(src, "vpi.in")).read() + "&gpu\n n_walkers = 1, device = 0, device_sampler = T\n/\n", str(tmp_path))
+    want = np.load(os.path.join(src, "final_worldline.npz"))["Path"]
+    got = np.fromfile(tmp_path / "worldlines_final.bin").reshape(want.shape)
+    assert same_bits(got, want)
+    assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL)
+    assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
+    assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()

@@ -166,7 +166,7 @@ def test_k6_config5_n256_321_beads_worm_sector(gpu_lib, oracle, name, threads, s
 @pytest.mark.parametrize("names", [["he4_wormbusy_s7", "he4_wormbusy_s8"],
                                    ["he4_worm_s1982", "he4_worm_s1983", "he4_worm_s1984"],
                                    ["he4_bis_cworm0_s1982", "he4_bis_cworm0_s1983"], ["he4_stock_short"],
-                                   ["he4_wf_analytic"]])
+                                   ["he4_wf_analytic"], ["he4_nlev1"]])
 @pytest.mark.parametrize("split", [0, 1])
 def test_k6_small_runs_full_state(gpu_lib, oracle, names, split):
     """The same full-state comparison on the small runs: dozens of accepted swaps, opens and closes, Npw = 1 and 2,

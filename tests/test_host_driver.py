@@ -40,7 +40,7 @@ def exe():
 
 
 @pytest.mark.parametrize("name", ["he4_worm_s1982", "ho1d_n2", "he4_stock_short", "he4_cworm0",
-                                  "he4_wormbusy_s7", "he4_wormbusy_s8", "he4_wf_analytic"])
+                                  "he4_wormbusy_s7", "he4_wormbusy_s8", "he4_wf_analytic", "he4_nlev1"])
 def test_front_end_reproduces_reference_files(exe, name, tmp_path):
     """he4_wormbusy_*: Npw = 2 partial waves in nr_vpi.out and dozens of accepted swaps (fort.99)."""
     src = os.path.join(RUNS, name)
