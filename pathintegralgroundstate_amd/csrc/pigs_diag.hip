@@ -197,6 +197,7 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
     // control state (meaningful in wave 0)
     int cv = -1, cmv = 3, clev = 0, cnl = 0, cii = 0, cseg = 0, ccur = 1, cp = 0;
     int c_nbd = 0, c_lgtpb = 0, c_kind = -1, c_phase = 0, c_pn = -1;
+    bool cv_seen = false;
     int pos = ctl[0];
     double nx[4] = {0.0, 0.0, 0.0, 0.0};
     int sink0 = 0, sink1 = 0, sink2 = 0;              // destinations of the slice-touch loads (see the task phase)
@@ -326,12 +327,18 @@ __global__ __launch_bounds__(NT, 1) void k_diag(
                     if (cv < V && isopen && cv % P.Np == pworm) ++cv;
                     if (cv >= V) quit = true;
                     else {
+                        // Two particles, one of them the open worm: every visit is to the SAME particle.  Its chain buffer is
+                        // kept current by the commits, whereas a copy fetched "a visit ahead" -- during this visit's first
+                        // phases -- would be stale by the time it is used (round 3 fuzz: Np = 2, Nlev = 5, CWorm > 0).  So a
+                        // visit to the particle just visited keeps the buffer, and nothing is fetched ahead for it.
+                        const int cp_prev = cv_seen ? cp : -1;
                         cp = cv % P.Np;
-                        ccur ^= 1;
+                        cv_seen = true;
+                        if (cp != cp_prev) ccur ^= 1;
                         c_phase = 0;
                         int vn = cv + 1;
                         if (vn < V && isopen && vn % P.Np == pworm) ++vn;
-                        c_pn = vn < V ? vn % P.Np : -1;
+                        c_pn = (vn < V && vn % P.Np != cp) ? vn % P.Np : -1;
                         cmv = (sp.do_cm && cv < P.Np) ? -1 : 0;               // -1: a TranslateChain visit
                         if (cmv == 0 && lane == 0) ++cnt[15];
                     }

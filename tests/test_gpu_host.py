@@ -252,7 +252,12 @@ def test_device_sampler_checkpoint_round_trip(exe, tmp_path):
     ("bis", "dim = 3, Np = 30, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 2", "0.4d0"),
     ("bis", "dim = 3, Np = 40, density = 0.25d0", "Nb = 24, Lstag = 10, Nlev = 4", "0.4d0"),
     # three 64-partner passes per bead: the end bead's eight (new | old) x pass tasks, TranslateChain on four CUs per walker
-    ("bis", "dim = 3, Np = 130, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 4", "0.4d0")])
+    ("bis", "dim = 3, Np = 130, density = 0.3d0", "Nb = 16, Lstag = 6, Nlev = 4", "0.4d0"),
+    # found by scripts/sampler_fuzz.py (round 3): Nlev = 1, the reference's default (head / tail moves still bisect 2^2 beads);
+    # two particles with an open worm in the stage-machine kernel (every visit to the same particle: no chain fetched ahead)
+    ("bis", "dim = 3, Np = 33, density = 0.2d0", "Nb = 12, Lstag = 6, Nlev = 1", "0.0d0"),
+    ("bis", "dim = 2, Np = 9, density = 0.2d0", "Nb = 8, Lstag = 6, Nlev = 1", "2.0d0"),
+    ("bis", "dim = 2, Np = 2, density = 0.2d0", "Nb = 33, Lstag = 13, Nlev = 5", "0.6d0")])
 def test_device_sampler_equals_host_driven_sampler_on_new_shapes(exe, tmp_path, sampling, extra, samp, cworm):
     """No reference run exists for these shapes; the host-driven sampler (bit-identical to the reference wherever
     a fixture exists) is the yardstick: same input, three walkers, device_sampler = F and T must give the same
