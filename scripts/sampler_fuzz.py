@@ -21,11 +21,16 @@ t0 = time.time()
 for case in range(ncase):
     dim = int(rng.integers(1, 4))
     trap = bool(rng.random() < 0.3)
-    Np = int(rng.choice([2, 3, 5, 9, 16, 21, 33, 64, 70])) if not trap else int(rng.choice([2, 3, 6, 9]))
-    Nb = int(rng.choice([4, 6, 8, 10, 12, 16, 20, 33]))
+    wide = os.environ.get("WIDE") == "1"       # larger systems, more walkers (slower per case)
+    if wide:
+        Np = int(rng.choice([2, 3, 4, 8, 17, 40, 65, 100, 130, 200, 256])) if not trap else int(rng.choice([2, 4, 7, 12, 20]))
+        Nb = int(rng.choice([4, 5, 9, 16, 24, 40, 64]))
+    else:
+        Np = int(rng.choice([2, 3, 5, 9, 16, 21, 33, 64, 70])) if not trap else int(rng.choice([2, 3, 6, 9]))
+        Nb = int(rng.choice([4, 6, 8, 10, 12, 16, 20, 33]))
     sampling = "bis" if rng.random() < 0.6 else "sta"
     cworm = float(rng.choice([0.0, 0.3, 0.6, 2.0]))
-    nlev_max = min(4 if trap else 6, int(np.floor(np.log2(2 * Nb))))
+    nlev_max = min(4 if trap else 7, int(np.floor(np.log2(2 * Nb))))
     Nlev = int(rng.integers(1, nlev_max + 1))
     Lstag = int(rng.integers(2, (Nb if cworm > 0 else 2 * Nb) + 1))
     Nstag = int(rng.integers(1, 4))
@@ -35,10 +40,12 @@ for case in range(ncase):
     wf_table = "T" if rng.random() < 0.75 else "F"
     dt = float(rng.choice([5e-3, 1e-2, 3e-2]))
     dens = float(rng.choice([0.05, 0.2, 0.365]))
-    NW = int(rng.choice([1, 2, 5]))
+    NW = int(rng.choice([1, 2, 5])) if not wide else int(rng.choice([1, 3, 7, 260], p=[0.4, 0.3, 0.25, 0.05]))
+    if wide and NW > 100 and Np > 20:
+        NW = 7
     G = 2 if (NW >= 2 and rng.random() < 0.3) else 1
     a_ho = " ".join(["1.0d0", "1.3d0", "0.8d0"][:dim])
-    nstep = 40
+    nstep = 40 if not wide else (12 if Np >= 100 else (20 if Np >= 40 else 40))
     inp = f"""&system
  dim = {dim}, Np = {Np}, density = {dens}d0, trap = {'T' if trap else 'F'}
 /
