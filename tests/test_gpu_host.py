@@ -525,3 +525,17 @@ def test_gpu_device_sampler_with_the_references_default_nlev_1(exe, tmp_path):
     assert _hex_close(tmp_path / "e_vpi.hex", src, mixed=MIXED_TOL)
     assert open(os.path.join(src, "nr_vpi.out"), "rb").read() == open(tmp_path / "nr_vpi.out", "rb").read()
     assert open(tmp_path / "perm_vpi.out").read().split() == open(os.path.join(src, "fort.99")).read().split()
+
+
+def test_sampler_fuzz_first_cases(exe):
+    """The first 16 cases of scripts/sampler_fuzz.py (seed 31337: the run that found the Nlev = 1 defect): random inputs through
+    the host-driven sampler, the device-resident sampler and the CPU twin with the reference's arithmetic, all bit-identical."""
+    import sys
+    shim = os.path.join(ROOT, "tests", "shim", "_build", "pigs_vpi")
+    if not os.path.exists(shim):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hostlib import build_cpu_host
+        build_cpu_host()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sampler_fuzz.py"), "16", "31337"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "16 cases, 0 failing" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
