@@ -83,6 +83,25 @@ for case in range(ncase):
             fail = f"arm {arm} rc={r.returncode}: " + open(os.path.join(d, "out.txt")).read()[-300:].replace("\n", " | ")
             break
         out[arm] = d
+    if fail is None and os.environ.get("RESUME", "1") == "1":
+        # checkpoint / resume of the device-resident sampler: block 1, stop, resume for block 2 == the straight two-block run
+        d = tempfile.mkdtemp()
+        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = T, checkpointing = T"
+        if G > 1:
+            gpu += f", n_gpus = {G}, same_device = T"
+        for part, txt in enumerate((inp.replace("Nblock = 2", "Nblock = 1"), inp.replace("Nblock = 2", "Nblock = 1").replace("resume = F", "resume = T"))):
+            with open(os.path.join(d, "vpi.in"), "w") as f:
+                f.write(txt + gpu + "\n/\n")
+            with open(os.path.join(d, "vpi.in")) as fin, open(os.path.join(d, f"out{part}.txt"), "w") as fo:
+                r = subprocess.run([EXE], stdin=fin, stdout=fo, stderr=subprocess.STDOUT, cwd=d, timeout=900)
+            if r.returncode != 0:
+                fail = f"resume arm part {part} rc={r.returncode}: " + open(os.path.join(d, f"out{part}.txt")).read()[-300:].replace("\n", " | ")
+                break
+        if fail is None:
+            wr = np.fromfile(os.path.join(d, "worldlines_final.bin"))
+            wt = np.fromfile(os.path.join(out["T"], "worldlines_final.bin"))
+            if not np.array_equal(wr.view(np.uint64), wt.view(np.uint64)):
+                fail = "device sampler: block 1 + resume for block 2 differs from the straight run"
     if fail is None:
         w = {a: np.fromfile(os.path.join(out[a], "worldlines_final.bin")) for a in out}
         if not (np.array_equal(w["F"].view(np.uint64), w["T"].view(np.uint64))):
@@ -90,12 +109,39 @@ for case in range(ncase):
         elif not np.array_equal(w["F"].view(np.uint64), w["C"].view(np.uint64)):
             fail = "GPU vs CPU twin: worldlines differ"
         else:
+            def hexrows(path):
+                import struct
+                rows = []
+                for ln in open(path):
+                    t = ln.split()
+                    if t:
+                        rows.append([float(int(t[0]))] + [struct.unpack(">d", bytes.fromhex(h))[0] for h in t[1:7]])
+                return np.array(rows, float).reshape(-1, 7)
             for wk in range(NW):
-                for nme in ("nr_vpi", "perm_vpi"):
+                for nme in ("nr_vpi", "perm_vpi", "gr_vpi"):      # integer-valued histograms: byte for byte
                     fn = f"{nme}.w{wk:04d}.out" if NW > 1 else f"{nme}.out"
                     pa, pb = os.path.join(out["F"], fn), os.path.join(out["T"], fn)
                     if os.path.exists(pa) and open(pa, "rb").read() != open(pb, "rb").read():
                         fail = f"{fn} differs between the samplers"
+                # block energies: the same kernels on the same worldlines in the two GPU arms -> the same bits; the CPU twin's
+                # (the oracle's) estimators to 1e-10 (E, K against |K|+|V|)
+                hn = f"e_vpi.w{wk:04d}.hex" if NW > 1 else "e_vpi.hex"
+                hf, ht, hc = (hexrows(os.path.join(out[a], hn)) for a in "FTC")
+                if hf.shape != ht.shape or not np.array_equal(hf.view(np.uint64), ht.view(np.uint64)):
+                    fail = f"{hn}: block energies differ between the two GPU arms"
+                elif hf.shape != hc.shape:
+                    fail = f"{hn}: number of diagonal blocks differs from the CPU twin"
+                elif len(hf):
+                    sc_e = np.abs(hc[:, 2]) + np.abs(hc[:, 3]); sc_t = np.abs(hc[:, 5]) + np.abs(hc[:, 6])
+                    scale = np.stack([sc_e, sc_e, np.abs(hc[:, 3]), sc_t, sc_t, np.abs(hc[:, 6])], 1)
+                    ok = np.isfinite(hc[:, 1:]) & (scale > 0)
+                    if np.any(np.abs(hf[:, 1:] - hc[:, 1:])[ok] > 1e-10 * scale[ok]):
+                        fail = f"{hn}: block energies differ from the CPU twin's beyond 1e-10: {np.max((np.abs(hf[:, 1:] - hc[:, 1:]) / np.where(scale > 0, scale, 1))[ok]):.2e}"
+                sn = f"sk_vpi.w{wk:04d}.out" if NW > 1 else "sk_vpi.out"
+                if not trap and os.path.exists(os.path.join(out["F"], sn)):
+                    a_, b_ = np.loadtxt(os.path.join(out["F"], sn)), np.loadtxt(os.path.join(out["T"], sn))
+                    if a_.shape != b_.shape or not np.allclose(a_, b_, rtol=1e-8, atol=1e-12, equal_nan=True):
+                        fail = f"{sn}: S(k) differs between the samplers"
     if fail:
         bad += 1
         print("FAIL", tag, "|", fail, flush=True)
