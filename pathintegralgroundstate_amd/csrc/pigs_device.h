@@ -133,6 +133,19 @@ __device__ __forceinline__ double div_by(double a, double d, double rd)
     return __builtin_fma(r, rd, q);
 }
 
+// The same for a numerator that may be +-Inf (a table head of a singular potential: V(0) = +Inf for r^-3 or r^-12): IEEE `/`
+// gives +-Inf, the residual step above Inf - Inf = NaN.  The reference's Delta S is then -Inf (a move AWAY from an overlap
+// below dr: accepted without a uniform) or +Inf (towards one: rejected), and NaN instead would freeze the particle for ever
+// (round 3 fuzz: 1D starts with two particles within dr).  One compare + select more; used where an infinite numerator can
+// arrive -- the force terms of the exact-term forms and the Chin-weight epilogue of every kernel -- not in the table-index path.
+__device__ __forceinline__ double div_by_inf(double a, double d, double rd)
+{
+    const double q = a * rd;
+    const double r = __builtin_fma(-q, d, a);
+    const double z = __builtin_fma(r, rd, q);
+    return __builtin_fabs(q) == __builtin_inf() ? q : z;
+}
+
 // s = RN(sqrt(x)) and y ~ 1/s from ONE v_rsq_f64 seed (Goldschmidt step + residual corrections).
 __device__ __forceinline__ void sqrt_rinv(double x, double &s, double &y)
 {
@@ -182,17 +195,17 @@ __device__ __forceinline__ FLerp flerp_setup(double x, const DevParams &P)
 template <typename TabPtr>
 __device__ __forceinline__ double finterp0(TabPtr F, const FLerp &L, const DevParams &P)
 {
-    return div_by(L.a1 * F[L.ix] + L.a2 * F[L.ix - 1], P.dr, P.rdr);
+    return div_by_inf(L.a1 * F[L.ix] + L.a2 * F[L.ix - 1], P.dr, P.rdr);      // (an infinite table head stays infinite)
 }
 
 template <typename TabPtr>
 __device__ __forceinline__ void finterp01(TabPtr F, const FLerp &L, const DevParams &P, double &v0, double &v1)
 {
     const double fm2 = F[L.im2], fm1 = F[L.ix - 1], f0 = F[L.ix], fp1 = F[L.ix + 1];
-    v0 = div_by(L.a1 * f0 + L.a2 * fm1, P.dr, P.rdr);
-    const double Fbefore = div_by(L.a1 * fm1 + L.a2 * fm2, P.dr, P.rdr);
-    const double Fafter  = div_by(L.a1 * fp1 + L.a2 * f0, P.dr, P.rdr);
-    v1 = div_by(0.5 * (Fafter - Fbefore), P.dr, P.rdr);
+    v0 = div_by_inf(L.a1 * f0 + L.a2 * fm1, P.dr, P.rdr);
+    const double Fbefore = div_by_inf(L.a1 * fm1 + L.a2 * fm2, P.dr, P.rdr);
+    const double Fafter  = div_by_inf(L.a1 * fp1 + L.a2 * f0, P.dr, P.rdr);
+    v1 = div_by_inf(0.5 * (Fafter - Fbefore), P.dr, P.rdr);
 }
 
 // ---- minimum image, branch-free form: d - copysign(L,d) where |d| > L/2.  Identical to the
@@ -379,10 +392,10 @@ __device__ __forceinline__ double green_function_action(int ib, int Nb, double d
     // VGPR pair (and spilled at the 128-VGPR budget of K1's pipe kernels); recomputing them per item is free
     double dt = dt_in;
     asm volatile("" : "+v"(dt));
-    if (ib == 0 || ib == 2 * Nb) return div_by(dt * Pot, 3.0, r3);
-    if ((ib & 1) == 0)           return div_by(2.0 * dt * Pot, 3.0, r3);
-    const double Vc = Pot + div_by(dt * dt * F2, 6.0, r6);
-    return div_by(4.0 * dt * Vc, 3.0, r3);
+    if (ib == 0 || ib == 2 * Nb) return div_by_inf(dt * Pot, 3.0, r3);
+    if ((ib & 1) == 0)           return div_by_inf(2.0 * dt * Pot, 3.0, r3);
+    const double Vc = Pot + div_by_inf(dt * dt * F2, 6.0, r6);
+    return div_by_inf(4.0 * dt * Vc, 3.0, r3);
 }
 
 // ---- analytic trial function, wf_table = F (the reference's DEFAULT, vpi_mod.f90:59): McMillan u(r) = -0.5 (Rm/r)^5 and

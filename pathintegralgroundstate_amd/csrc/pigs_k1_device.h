@@ -72,7 +72,7 @@ __device__ __forceinline__ void pair_accumulate(const DevParams &P, VTab VT, con
         if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
-            const double f = div_by(dv * d[k], r, rinv);            // (dv*xij(k))/rij
+            const double f = div_by_inf(dv * d[k], r, rinv);        // (dv*xij(k))/rij  (dv = +-Inf below dr of a singular table)
             if (IS_OLD) A.fO[k] = A.fO[k] + f; else A.fN[k] = A.fN[k] + f;
         }
     } else {
@@ -397,11 +397,14 @@ __device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const 
     const double f  = __builtin_amdgcn_fract(t);
     const double *V = VT.p + i0;
     const double F0 = V[0], F1 = V[1];
-    const double v  = __builtin_fma(f, F1 - F0, F0);
+    // f F1 + (1-f) F0 as two products: a table head of +Inf (singular potentials, r < 2 dr) then gives +Inf as the reference's
+    // (a1 F(ix) + a2 F(ix-1))/dx does, where F0 + f (F1 - F0) gave Inf - Inf = NaN (round 3 fuzz); one instruction more per distance
+    const double omf = 1.0 - f;
+    const double v   = __builtin_fma(f, F1, omf * F0);
     if (IS_OLD) A.potO = A.potO + v; else A.potN = A.potN + v;
     if (CLS == CLS_ODD) {
         const double Fm = V[-1], Fp = V[2];
-        const double D  = __builtin_fma(f, (Fp - F1) - (F0 - Fm), F1 - Fm);
+        const double D  = __builtin_fma(f, Fp, omf * F1) - __builtin_fma(f, F0, omf * Fm);    // Fafter - Fbefore of interpolate.f90, in cell units
         const double s  = D * (h * P.rdr);                                // ((Fafter-Fbefore)*0.5/dr) * (2h)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
@@ -416,7 +419,7 @@ __device__ __forceinline__ void pipe_pair(const DevParams &P, PipeTab VT, const 
 #else
             const double *U = WF + (in ? it : 0);
             const double u0 = U[0], u1 = U[1];
-            u = in ? __builtin_fma(f, u1, (1.0 - f) * u0) : 0.0;              // (1-f)*(-Inf) keeps the -Inf head (Q4)
+            u = in ? __builtin_fma(f, u1, omf * u0) : 0.0;                    // (1-f)*(-Inf) keeps the -Inf head (Q4)
 #endif
         } else {
             u = in ? log_psi(0, P.Rm, g) : 0.0;                               // analytic trial function (wf_table = F)

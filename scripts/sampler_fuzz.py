@@ -45,6 +45,8 @@ for case in range(ncase):
         NW = 7
     G = 2 if (NW >= 2 and rng.random() < 0.3) else 1
     a_ho = " ".join(["1.0d0", "1.3d0", "0.8d0"][:dim])
+    pot = str(rng.choice(["aziz2", "aziz2", "lj", "dipolar"]))          # the reference compiles ONE potential in; the table kinds are an input here
+    k1v = int(rng.choice([0, 0, 2]))                                     # Delta-S kernel of the host-driven arm: default short arithmetic / exact-term
     nstep = 40 if not wide else (12 if Np >= 100 else (20 if Np >= 40 else 40))
     inp = f"""&system
  dim = {dim}, Np = {Np}, density = {dens}d0, trap = {'T' if trap else 'F'}
@@ -67,12 +69,14 @@ for case in range(ncase):
 /
 """
     tag = (f"case {case}: dim={dim} Np={Np} Nb={Nb} {sampling} Lstag={Lstag} Nlev={Nlev} Nstag={Nstag} CMFreq={CMFreq} CWorm={cworm} "
-           f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G}")
+           f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G} potential={pot} k1_variant(F)={k1v}")
     out = {}
     fail = None
     for arm in "FTC":
         d = tempfile.mkdtemp()
-        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = {'T' if arm == 'T' else 'F'}, checkpointing = F"
+        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = {'T' if arm == 'T' else 'F'}, checkpointing = F, potential = '{pot}'"
+        if arm == "F" and k1v:
+            gpu += f", k1_variant = {k1v}"
         if G > 1:
             gpu += f", n_gpus = {G}, same_device = T"
         with open(os.path.join(d, "vpi.in"), "w") as f:
@@ -86,7 +90,7 @@ for case in range(ncase):
     if fail is None and os.environ.get("RESUME", "1") == "1":
         # checkpoint / resume of the device-resident sampler: block 1, stop, resume for block 2 == the straight two-block run
         d = tempfile.mkdtemp()
-        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = T, checkpointing = T"
+        gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = T, checkpointing = T, potential = '{pot}'"
         if G > 1:
             gpu += f", n_gpus = {G}, same_device = T"
         for part, txt in enumerate((inp.replace("Nblock = 2", "Nblock = 1"), inp.replace("Nblock = 2", "Nblock = 1").replace("resume = F", "resume = T"))):

@@ -115,8 +115,13 @@ def block_energy_errors(rows, want):
     sc_e = np.abs(want[:, 1]) + np.abs(want[:, 2])
     sc_t = np.abs(want[:, 4]) + np.abs(want[:, 5])
     d = np.abs(rows - want)
-    mixed = d[:, 0:2] / sc_e[:, None]
-    rest = np.stack([d[:, 2] / np.abs(want[:, 2]), d[:, 3] / sc_t, d[:, 4] / sc_t, d[:, 5] / np.abs(want[:, 5])], 1)
+
+    def ratio(num, den):                  # identical values are zero error also where the scale vanishes (two particles
+        with np.errstate(all="ignore"):   # beyond each other's cutoff: V = 0 exactly)
+            return np.where(num == 0, 0.0, num / den)
+    mixed = ratio(d[:, 0:2], sc_e[:, None])
+    rest = np.stack([ratio(d[:, 2], np.abs(want[:, 2])), ratio(d[:, 3], sc_t), ratio(d[:, 4], sc_t),
+                     ratio(d[:, 5], np.abs(want[:, 5]))], 1)
     return mixed, rest
 
 

@@ -731,3 +731,47 @@ def test_device_log_is_the_host_libm_log_bit_for_bit(gpu_lib):
     with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
         bad, x = ctx.selftest_log(1 << 30, seed=20261004)
     assert bad == 0, (bad, float(x).hex())
+
+
+@pytest.mark.parametrize("pot", ["dipolar", "lj"])
+def test_infinite_table_head_gives_the_references_infinities(gpu_lib, oracle, pot):
+    """Singular potentials tabulate V(0) = +Inf (vpi_mod.f90:96-110 fills cell 1 at r = 0).  A pair closer than 3 dr then has
+    an infinite V (r < 2 dr) or an infinite dV/dr (the derivative stencil reaches cell 1 up to r < 3 dr), and the reference's
+    Delta S is -Inf for a move AWAY from such a pair (accepted without a uniform), +Inf towards one (rejected), NaN between
+    two such places.  Rounds 1-2 returned NaN for all of them -- the exact short divisions and the one-product interpolation
+    turn Inf into Inf - Inf -- so a particle that started within 3 dr of another could never move again (round 3's sampler
+    fuzz: 1D random starts).  Every K1 variant now returns the reference's value, infinities and NaNs included."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    cfg = SystemConfig(dim=1, Np=21, Nb=12, density=0.2, dt=5e-3, Rm=1.1, Nmax=4000)
+    S = System(dim=1, Np=21, Nb=12, density=0.2, dt=5e-3, Rm=1.1, Nmax=4000)
+    VT, WF = gpu_lib.build_tables(cfg, pot)
+    assert np.isinf(VT[1])
+    L, dr = S.Lbox[0], S.dr
+    P = np.zeros((S.M, S.Np, 1))
+    P[:, :, 0] = (np.arange(S.Np) - 10) * 4.9                       # a regular line ...
+    for j, gap in enumerate((0.5, 1.5, 2.5, 3.5)):                  # ... with four close pairs: inside and just outside the zone
+        P[:, 2 * j + 1, 0] = P[:, 2 * j, 0] + gap * dr
+    ip, ib, xn, xo = [], [], [], []
+    for j in range(4):
+        for b in (0, 1, 2, 2 * S.Nb):                                # end, odd, even, end
+            p = 2 * j + 2                                            # 1-based index of the second particle of pair j
+            for target in (1.0, 0.7 * dr + P[b, 2 * j, 0] - P[b, 2 * j + 1, 0]):     # away from the pair / onto another place inside the zone
+                ip.append(p); ib.append(b); xo.append(P[b, p - 1].copy()); xn.append(P[b, p - 1] + target)
+    # and a far particle moved INTO the zone of pair 0
+    for b in (0, 1, 2):
+        ip.append(21); ib.append(b); xo.append(P[b, 20].copy()); xn.append(P[b, 0] + 0.3 * dr)
+    ip, ib = np.array(ip, np.int32), np.array(ib, np.int32)
+    xn, xo = np.array(xn), np.array(xo)
+    w = np.zeros(len(ip), np.int32)
+    want = oracle.delta_action_batch(S, WF, VT, P[None], w, ip, ib, xn, xo)
+    assert np.isneginf(want).any() and np.isposinf(want).any()
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=1) as ctx:
+        ctx.upload_all(P[None])
+        for v in (0, 1, 2, 7, 8, 12, 13, 14):
+            ctx.set_tuning("k1_variant", v)
+            got = ctx.delta_action_batch(w, ip, ib, xn, xo)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (v, got, want)
+            assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)), (v, got, want)
+            fin = np.isfinite(want)
+            assert np.all(np.abs(got[fin] - want[fin]) <= 1e-9 * np.abs(want[fin]) + 1e-12), v
