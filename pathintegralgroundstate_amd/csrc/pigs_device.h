@@ -228,8 +228,8 @@ __device__ __forceinline__ double min_image_fast(double (&x)[DIM], const DevPara
 
 // ---- short-arithmetic forms (K1 variant "fast", selected by passing the table as a FastTab) ----
 // Same quantities as above to ~1 ulp per term instead of the reference's exact rounding sequence:
-//   * minimum image as v - L*rint(v/L): identical result to the two compares except for |v| within an
-//     ulp of L/2 exactly, where the pair is outside the cutoff anyway (r >= L/2 >= rcut);
+//   * minimum image as v - sign(v)*L*rint(min(|v|/L,1)): identical result to the two compares except for |v|
+//     within an ulp of L/2 exactly, where the pair is outside the cutoff anyway (r >= L/2 >= rcut);
 //   * r^2 keeps the reference's rounding sequence, so the cutoff decision r2 <= rcut2 is unchanged;
 //   * sqrt / 1/r from one v_rsq_f64 + one coupled Newton step (r to < 1 ulp, 1/r to ~1e-14);
 //   * interpolation in the normalised cell coordinate f = r/dr - int(r/dr): f*F[i+1] + (1-f)*F[i]
@@ -249,7 +249,11 @@ __device__ __forceinline__ double min_image_rn(double (&x)[DIM], const DevParams
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         const double v = x[k];
-        const double n = __builtin_rint(v * P.rLbox[k]);
+        // ONE fold at most, as pbc_mod.f90:40-41: |n| = rint(min(|v|/L, 1)) is 0 or 1 (the min/max pair is the VOP3 clamp
+        // modifier of the multiply).  A plain rint(v/L) folds a |v| > 1.5 L twice where the reference leaves it outside
+        // the cutoff -- reachable in a small box by the long free segments of a head / tail move (round 3 fuzz).
+        const double t = __builtin_fmin(__builtin_fmax(__builtin_fabs(v) * P.rLbox[k], 0.0), 1.0);
+        const double n = __builtin_copysign(__builtin_rint(t), v);      // one v_bfi_b32 on the high word
         const double u = __builtin_fma(-P.Lbox[k], n, v);
         x[k] = u;
         r2 = r2 + u * u;                                          // the reference's rounding sequence

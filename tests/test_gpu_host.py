@@ -539,3 +539,47 @@ def test_sampler_fuzz_first_cases(exe):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sampler_fuzz.py"), "16", "31337"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "16 cases, 0 failing" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_small_box_with_long_free_end_segments_vs_the_cpu_twin(exe, tmp_path):
+    """Case 241 of `WIDE=1 scripts/sampler_fuzz.py 260 777`: two particles in a box of L = 2.15, head / tail moves over up to
+    2^7 links at dt = 0.03 (a free spread of ~ L).  Their proposals land several L away, BoundaryConditions folds them once
+    (pbc_mod.f90:20-21) and MinimumImage folds a separation once (pbc_mod.f90:40-41): what is beyond 1.5 L stays outside the
+    cutoff.  The short-arithmetic minimum image folded by rint(v/L) -- all the way -- and step 37 took another decision than
+    the reference's arithmetic.  Host-driven sampler, device-resident sampler and the CPU twin (tests/shim + oracle) are
+    bit-identical again after 40 MC steps."""
+    import sys
+    shim = os.path.join(ROOT, "tests", "shim", "_build", "pigs_vpi")
+    if not os.path.exists(shim):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hostlib import build_cpu_host
+        build_cpu_host()
+    inp = """&system
+ dim = 3, Np = 2, density = 0.2d0, trap = F
+/
+&samp
+ resume = F, dt = 0.03d0, Nb = 64, seed = 1241, delta_cm = 0.2d0, CMFreq = 1,
+ sampling = 'bis', Lstag = 36, Nlev = 7, Nstag = 2, Nblock = 2, Nstep = 20, Nbin = 40, Nk = 6
+/
+&obdm
+ swapping = T, Nobdm = 3, Npw = 0, CWorm = 2.0d0
+/
+&wavefun
+ Nmax = 4000, wf_table = T, v_table = T
+/
+&jastrow
+ Rm = 1.10d0
+/
+&extpot
+ a_ho = 1.0d0 1.3d0 0.8d0
+/
+"""
+    out = {}
+    for arm in "FTC":
+        d = tmp_path / arm
+        d.mkdir()
+        _run(shim if arm == "C" else exe, inp + f"&gpu\n n_walkers = 1, device = 0, device_sampler = {'T' if arm == 'T' else 'F'}, "
+             "checkpointing = F, potential = 'dipolar'\n/\n", str(d))
+        out[arm] = np.fromfile(d / "worldlines_final.bin")
+    assert same_bits(out["F"], out["C"]), "host-driven sampler vs CPU twin"
+    assert same_bits(out["T"], out["C"]), "device-resident sampler vs CPU twin"

@@ -775,3 +775,45 @@ def test_infinite_table_head_gives_the_references_infinities(gpu_lib, oracle, po
             assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)), (v, got, want)
             fin = np.isfinite(want)
             assert np.all(np.abs(got[fin] - want[fin]) <= 1e-9 * np.abs(want[fin]) + 1e-12), v
+
+
+@pytest.mark.parametrize("dim,Np", [(3, 2), (3, 4), (2, 3), (1, 5)])
+def test_beads_far_outside_the_box_fold_once_like_the_reference(gpu_lib, oracle, dim, Np):
+    """pbc_mod.f90:40-41 folds a separation ONCE (two compares), and BoundaryConditions (pbc_mod.f90:20-21) folds a proposal
+    once: in a small box the long free segment of a head / tail move (Nlev' up to 7 -> 128 links) puts beads several box
+    lengths away, and a separation beyond 1.5 L stays outside the cutoff in the reference.  The short-arithmetic minimum
+    image of rounds 1-2 (v - L rint(v/L)) folded it all the way and found a pair inside the cutoff that the reference
+    does not see (round 3's WIDE sampler fuzz, Np = 2, Nlev = 7: one decision in 40 000 items).  Every K1 variant against
+    the oracle with resident beads up to 3 L and proposals up to 5 L from the origin."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    kw = dict(dim=dim, Np=Np, Nb=16, density=0.2, dt=0.03)
+    S = System(**kw)
+    cfg = SystemConfig(**kw)
+    VT, WF = oracle.tables(S)
+    L = np.asarray(S.Lbox[:dim])
+    rng = np.random.default_rng(100 * dim + Np)
+    W, n = 3, 3000
+    Paths = rng.uniform(-3.0, 3.0, (W, S.M, Np, dim)) * L
+    Paths[:, ::3] = rng.uniform(-0.5, 0.5, Paths[:, ::3].shape) * L          # a third of the slices inside the box
+    w = rng.integers(0, W, n).astype(np.int32)
+    ip = rng.integers(1, Np + 1, n).astype(np.int32)
+    ib = rng.integers(0, S.M, n).astype(np.int32)
+    xold = Paths[w, ib, ip - 1].copy()
+    xnew = rng.uniform(-5.0, 5.0, xold.shape) * L
+    xnew[::2] = rng.uniform(-1.0, 1.0, xnew[::2].shape) * L
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w, ip, ib, xnew, xold)
+    fin = np.isfinite(want)
+    assert fin.sum() > n // 2 and np.count_nonzero(want[fin]) > n // 8
+    u = rng.uniform(size=n)
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        for v in (0, 1, 2, 7, 8, 12, 13, 14):
+            ctx.set_tuning("k1_variant", v)
+            got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), v
+            assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), v
+            bad = np.abs(got - want)[fin] > 1e-9 * np.abs(want[fin]) + 1e-10
+            assert not bad.any(), (v, int(bad.sum()), got[fin][bad][:3], want[fin][bad][:3])
+            with np.errstate(over="ignore", invalid="ignore"):
+                assert np.array_equal(np.exp(-got) >= u, np.exp(-want) >= u), v
