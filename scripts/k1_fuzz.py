@@ -48,12 +48,15 @@ for case in range(ncase):
     W = int(rng.integers(1, 4))
     L = np.asarray(S.Lbox[:dim])
     Paths = []
+    far = (not trap) and rng.random() < 0.35          # separations beyond 1.5 L: the reference folds once and leaves them outside the cutoff
     for w in range(W):
         P, _ = o.init_path(S, 100 + case * 7 + w)
         P = P + rng.normal(0, 0.12 if not trap else 0.3, P.shape)
         if not trap:
             P = np.where(P > L / 2, P - L, P)
             P = np.where(P < -L / 2, P + L, P)
+            if far:                      # beads left outside the box by ONE fold of a far proposal (pbc_mod.f90:20-21)
+                P = P + L * rng.integers(-3, 4, P.shape) * (rng.random(P.shape) < 0.15)
         Paths.append(P)
     Paths = np.stack(Paths)
     n = 300
@@ -62,7 +65,7 @@ for case in range(ncase):
     ib = rng.integers(0, S.M, n).astype(np.int32)
     ib[:8] = [0, 2 * Nb, 0, 2 * Nb, min(1, 2 * Nb), max(2 * Nb - 1, 0), Nb, Nb]          # end beads, odd and even ones
     xold = Paths[wv, ib, ip - 1].copy()
-    xnew = xold + rng.normal(0, 0.1, xold.shape)
+    xnew = xold + rng.normal(0, 0.1, xold.shape) * (1.0 if not far else np.where(rng.random((n, 1)) < 0.5, 1.0, 30.0 * float(L.max())))
     if not trap:
         xnew = np.where(xnew > L / 2, xnew - L, xnew)
         xnew = np.where(xnew < -L / 2, xnew + L, xnew)
@@ -121,7 +124,7 @@ for case in range(ncase):
             Q[wv[i], ib[i], ip[i] - 1] = xnew[i]
         if not same_bits(ctx.download_all(), Q):
             msgs.append("commit_beads")
-    tag = f"case {case}: dim={dim} Np={Np} Nb={Nb} Nmax={Nmax} trap={trap} wf_table={wf_table} W={W} variants={variants}"
+    tag = f"case {case}: dim={dim} Np={Np} Nb={Nb} Nmax={Nmax} trap={trap} wf_table={wf_table} W={W} far={far} variants={variants}"
     if msgs:
         bad += 1
         print("FAIL", tag, "|", "; ".join(msgs), flush=True)

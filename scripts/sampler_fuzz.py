@@ -70,10 +70,14 @@ for case in range(ncase):
 """
     tag = (f"case {case}: dim={dim} Np={Np} Nb={Nb} {sampling} Lstag={Lstag} Nlev={Nlev} Nstag={Nstag} CMFreq={CMFreq} CWorm={cworm} "
            f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G} potential={pot} k1_variant(F)={k1v}")
+    if os.environ.get("ONLY") and case != int(os.environ["ONLY"]):      # ONLY=<case>: that case of the sequence alone
+        continue
     out = {}
     fail = None
     for arm in "FTC":
-        d = tempfile.mkdtemp()
+        d = tempfile.mkdtemp(dir=os.environ.get("KEEP"))                # KEEP=<dir>: the arms' working directories stay there
+        if os.environ.get("KEEP"):
+            print("arm", arm, d, flush=True)
         gpu = f"&gpu\n n_walkers = {NW}, device = 0, device_sampler = {'T' if arm == 'T' else 'F'}, checkpointing = F, potential = '{pot}'"
         if arm == "F" and k1v:
             gpu += f", k1_variant = {k1v}"
@@ -144,7 +148,15 @@ for case in range(ncase):
                 sn = f"sk_vpi.w{wk:04d}.out" if NW > 1 else "sk_vpi.out"
                 if not trap and os.path.exists(os.path.join(out["F"], sn)):
                     a_, b_ = np.loadtxt(os.path.join(out["F"], sn)), np.loadtxt(os.path.join(out["T"], sn))
-                    if a_.shape != b_.shape or not np.allclose(a_, b_, rtol=1e-8, atol=1e-12, equal_nan=True):
+                    # host libm cos / sin (host-driven arm: sample_mod.f90:430-470 on the mirror) against the device library's in
+                    # k_structure: S(k) itself to 1e-8; its error bar is the root of <S^2> - <S>^2 over two blocks -- a difference
+                    # of 1e-11 between numbers of the size of S^2 -- and is compared on the scale of S (round 3: WIDE seed 4242 case 24)
+                    ok_ = a_.shape == b_.shape
+                    if ok_:
+                        a3, b3 = a_.reshape(-1, 3), b_.reshape(-1, 3)           # (q, S, error bar) per direction and q
+                        ok_ = np.allclose(a3[:, :2], b3[:, :2], rtol=1e-8, atol=1e-12, equal_nan=True) and \
+                            bool(np.all((np.abs(a3[:, 2] - b3[:, 2]) <= 1e-8 * (np.abs(a3[:, 1]) + np.abs(a3[:, 2])) + 1e-12) | (np.isnan(a3[:, 2]) & np.isnan(b3[:, 2]))))
+                    if not ok_:
                         fail = f"{sn}: S(k) differs between the samplers"
     if fail:
         bad += 1
