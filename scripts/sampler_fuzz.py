@@ -28,6 +28,11 @@ for case in range(ncase):
     else:
         Np = int(rng.choice([2, 3, 5, 9, 16, 21, 33, 64, 70])) if not trap else int(rng.choice([2, 3, 6, 9]))
         Nb = int(rng.choice([4, 6, 8, 10, 12, 16, 20, 33]))
+    small = os.environ.get("SMALL") == "1"     # tiny periodic boxes with long free segments: separations of several box lengths
+    if small:
+        trap = False
+        Np = int(rng.choice([2, 3, 4, 6]))
+        Nb = int(rng.choice([24, 40, 64]))
     sampling = "bis" if rng.random() < 0.6 else "sta"
     cworm = float(rng.choice([0.0, 0.3, 0.6, 2.0]))
     nlev_max = min(4 if trap else 7, int(np.floor(np.log2(2 * Nb))))
@@ -40,6 +45,9 @@ for case in range(ncase):
     wf_table = "T" if rng.random() < 0.75 else "F"
     dt = float(rng.choice([5e-3, 1e-2, 3e-2]))
     dens = float(rng.choice([0.05, 0.2, 0.365]))
+    if small:
+        dt = float(rng.choice([3e-2, 6e-2]))
+        dens = float(rng.choice([0.2, 0.365, 0.6]))
     NW = int(rng.choice([1, 2, 5])) if not wide else int(rng.choice([1, 3, 7, 260], p=[0.4, 0.3, 0.25, 0.05]))
     if wide and NW > 100 and Np > 20:
         NW = 7
