@@ -206,8 +206,10 @@ __global__ __launch_bounds__(1024) void k_slice_energy_lds(
                     const FCell C = fcell_setup(__builtin_fmax(r2, 1e-300), P);
                     const double *V = VT.p + (in ? C.i0 : VT.zc);
                     const double Fm = V[-1], F0 = V[0], F1 = V[1], Fp = V[2];
-                    poti = poti + __builtin_fma(C.f, F1 - F0, F0);
-                    const double D = __builtin_fma(C.f, (Fp - F1) - (F0 - Fm), F1 - Fm);
+                    // two products per interpolation, as pipe_pair (pigs_k1_device.h): a +Inf table head stays +Inf
+                    // where F0 + f (F1 - F0) makes Inf - Inf
+                    poti = poti + __builtin_fma(C.f, F1, C.omf * F0);
+                    const double D = __builtin_fma(C.f, Fp, C.omf * F1) - __builtin_fma(C.f, F0, C.omf * Fm);
                     const double sc = D * (C.rinv * P.hrdr);
 #pragma unroll
                     for (int k = 0; k < DIM; ++k) F[k] = __builtin_fma(sc, d[k], F[k]);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_slice_energy_lds(
                     const double r2 = min_image_rn<DIM>(d, P);
                     const FCell C = fcell_setup(__builtin_fmax(r2, 1e-300), P);
                     const double *V = VT.p + (r2 <= P.rcut2 ? C.i0 : VT.zc);
-                    poti = poti + __builtin_fma(C.f, V[1] - V[0], V[0]);
+                    poti = poti + __builtin_fma(C.f, V[1], C.omf * V[0]);
                 }
             }
             pot = poti;

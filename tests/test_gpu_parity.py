@@ -817,3 +817,46 @@ def test_beads_far_outside_the_box_fold_once_like_the_reference(gpu_lib, oracle,
             assert not bad.any(), (v, int(bad.sum()), got[fin][bad][:3], want[fin][bad][:3])
             with np.errstate(over="ignore", invalid="ignore"):
                 assert np.array_equal(np.exp(-got) >= u, np.exp(-want) >= u), v
+
+
+@pytest.mark.parametrize("W", [2, 96])
+def test_estimators_near_an_infinite_table_head(gpu_lib, oracle, W):
+    """The estimators on worldlines with pairs inside the +Inf head of a singular table (see
+    test_infinite_table_head_gives_the_references_infinities): PotentialEnergy / ThermEnergy / LocalEnergy return what the
+    reference's arithmetic returns -- +-Inf where it does, NaN where it does (Inf - Inf), the finite values elsewhere.
+    W = 2: the per-slice kernels; W = 96 (2 304 slices): the persistent LDS-table form of K2, whose one-product interpolation
+    F0 + f (F1 - F0) turned the head into NaN until round 3."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    kw = dict(dim=1, Np=21, Nb=12, density=0.2, dt=5e-3, Rm=1.1, Nmax=4000)
+    cfg, S = SystemConfig(**kw), System(**kw)
+    VT, WF = gpu_lib.build_tables(cfg, "dipolar")
+    assert np.isinf(VT[1])
+    dr = S.dr
+    rng = np.random.default_rng(5)
+    Paths = np.zeros((W, S.M, S.Np, 1))
+    for w in range(W):
+        Paths[w, :, :, 0] = (np.arange(S.Np) - 10) * 4.9 + rng.normal(0, 0.05, (S.M, S.Np))
+        if w % 2 == 0:                                                   # every other walker: close pairs on some slices
+            for j, gap in enumerate((0.5, 1.5, 2.5, 3.5)):
+                for b in (0, 3, 4, 2 * S.Nb, S.Nb):
+                    Paths[w, (b + j) % S.M, 2 * j + 1, 0] = Paths[w, (b + j) % S.M, 2 * j, 0] + gap * dr
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        E, Ec, Ep = ctx.therm_energy_batch()
+        le0 = ctx.local_energy_batch(0)
+    seen_inf = False
+    for w in list(range(min(W, 6))) + ([W - 2, W - 1] if W > 6 else []):
+        want = np.array(oracle.therm_energy(S, VT, Paths[w]))
+        got = np.array([E[w], Ec[w], Ep[w]])
+        seen_inf |= bool(np.any(~np.isfinite(want)))
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (w, got, want)
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)), (w, got, want)
+        fin = np.isfinite(want)
+        assert np.all(np.abs(got[fin] - want[fin]) <= 1e-10 * np.abs(want[fin])), (w, got, want)
+        lo = np.array(oracle.local_energy(S, WF, VT, Paths[w][0]))
+        lg = np.array([le0[0][w], le0[1][w], le0[2][w]])
+        assert np.array_equal(np.isnan(lg), np.isnan(lo)) and np.array_equal(np.isposinf(lg), np.isposinf(lo)), (w, lg, lo)
+        fin = np.isfinite(lo)
+        assert np.all(np.abs(lg[fin] - lo[fin]) <= 1e-10 * (np.abs(lo[1]) + np.abs(lo[2]))), (w, lg, lo)
+    assert seen_inf
