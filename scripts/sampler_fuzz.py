@@ -53,31 +53,41 @@ for case in range(ncase):
         NW = 7
     G = 2 if (NW >= 2 and rng.random() < 0.3) else 1
     a_ho = " ".join(["1.0d0", "1.3d0", "0.8d0"][:dim])
+    # later additions (drawn last, so that the earlier records' case numbers keep their inputs when MORE is unset): the width of
+    # the TranslateChain shift (up to several box lengths in a small box: beads left outside the box by the ONE fold of
+    # BoundaryConditions), the Jastrow range, swapping off (quirk Q9: only without a worm)
+    more = os.environ.get("MORE") == "1"
+    delta_cm, Rm, swapping = 0.2, 1.10, "T"
     pot = str(rng.choice(["aziz2", "aziz2", "lj", "dipolar"]))          # the reference compiles ONE potential in; the table kinds are an input here
     k1v = int(rng.choice([0, 0, 2]))                                     # Delta-S kernel of the host-driven arm: default short arithmetic / exact-term
     nstep = 40 if not wide else (12 if Np >= 100 else (20 if Np >= 40 else 40))
+    if more:
+        delta_cm = float(rng.choice([0.05, 0.2, 1.0, 4.0, 9.0]))
+        Rm = float(rng.choice([0.9, 1.1, 1.4]))
+        if cworm == 0.0 and rng.random() < 0.3:
+            swapping = "F"
     inp = f"""&system
  dim = {dim}, Np = {Np}, density = {dens}d0, trap = {'T' if trap else 'F'}
 /
 &samp
- resume = F, dt = {dt}d0, Nb = {Nb}, seed = {1000 + case}, delta_cm = 0.2d0, CMFreq = {CMFreq},
+ resume = F, dt = {dt}d0, Nb = {Nb}, seed = {1000 + case}, delta_cm = {delta_cm}d0, CMFreq = {CMFreq},
  sampling = '{sampling}', Lstag = {Lstag}, Nlev = {Nlev}, Nstag = {Nstag}, Nblock = 2, Nstep = {nstep // 2}, Nbin = 40, Nk = 6
 /
 &obdm
- swapping = T, Nobdm = {Nobdm}, Npw = {Npw}, CWorm = {cworm}d0
+ swapping = {swapping}, Nobdm = {Nobdm}, Npw = {Npw}, CWorm = {cworm}d0
 /
 &wavefun
  Nmax = 4000, wf_table = {wf_table}, v_table = T
 /
 &jastrow
- Rm = 1.10d0
+ Rm = {Rm}d0
 /
 &extpot
  a_ho = {a_ho}
 /
 """
     tag = (f"case {case}: dim={dim} Np={Np} Nb={Nb} {sampling} Lstag={Lstag} Nlev={Nlev} Nstag={Nstag} CMFreq={CMFreq} CWorm={cworm} "
-           f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G} potential={pot} k1_variant(F)={k1v}")
+           f"Nobdm={Nobdm} Npw={Npw} trap={trap} wf_table={wf_table} dt={dt} rho={dens} walkers={NW} shards={G} potential={pot} k1_variant(F)={k1v}" + (f" delta_cm={delta_cm} Rm={Rm} swapping={swapping}" if more else ""))
     if os.environ.get("ONLY") and case != int(os.environ["ONLY"]):      # ONLY=<case>: that case of the sequence alone
         continue
     out = {}
