@@ -16,10 +16,14 @@
  * although the builders fill it at (i-1)*dx (Q1: kept, not fixed).          */
 double po_interpolate(int opt, int N, double dx, const double *F, double x)
 {
-    (void)N;
     int    ix   = (int)(x / dx) + 1;            /* interpolate.f90:13 */
     double aux1 = x - (double)(ix - 1) * dx;    /* :14 */
     double aux2 = dx - aux1;                    /* :15 */
+    /* Beyond the table's last cell the reference reads F out of bounds: undefined.  Only a TRAPPED system gets there (no
+     * cutoff: a pair farther apart than rcut = 30 a_ho, vpi.f90:84-92 -- round 3's fuzz with TranslateChain shifts of 9 a_ho).
+     * The product clamps the cell index (pigs_device.h lerp_setup / flerp_setup) and so does this checker: an identity for
+     * every r <= rcut, i.e. wherever the reference is defined. */
+    if (ix > N) ix = N;
 
     if (opt == 0) {
         return (aux1 * F[ix] + aux2 * F[ix - 1]) / dx;                 /* :21 */

@@ -20,7 +20,7 @@ bad = 0
 t0 = time.time()
 for case in range(ncase):
     dim = int(rng.integers(1, 4))
-    trap = bool(rng.random() < 0.3)
+    trap = bool(rng.random() < 0.3) or os.environ.get("TRAP") == "1"        # TRAP=1: trapped systems only
     wide = os.environ.get("WIDE") == "1"       # larger systems, more walkers (slower per case)
     if wide:
         Np = int(rng.choice([2, 3, 4, 8, 17, 40, 65, 100, 130, 200, 256])) if not trap else int(rng.choice([2, 4, 7, 12, 20]))

@@ -860,3 +860,44 @@ def test_estimators_near_an_infinite_table_head(gpu_lib, oracle, W):
         fin = np.isfinite(lo)
         assert np.all(np.abs(lg[fin] - lo[fin]) <= 1e-10 * (np.abs(lo[1]) + np.abs(lo[2]))), (w, lg, lo)
     assert seen_inf
+
+
+def test_trap_pairs_beyond_the_table_are_clamped_not_read_out_of_bounds(gpu_lib, oracle):
+    """A trapped system has no cutoff (vpi_mod.f90:2699-2722 evaluate every pair) and its tables end at rcut = 30 a_ho
+    (vpi.f90:84-92): for a pair farther apart the reference reads VTable / LogWF out of bounds -- undefined.  The product clamps
+    the cell index to the last cell (lerp_setup / flerp_setup: an identity wherever the reference is defined) instead of reading
+    whatever lies behind the table; the oracle does the same, so that the two can be compared there at all (round 3's fuzz with
+    TranslateChain shifts of 9 a_ho).  Delta S on every trap variant, ThermEnergy and LocalEnergy."""
+    from oracle.pyoracle import System
+    from pathintegralgroundstate_amd import SystemConfig
+    kw = dict(dim=1, Np=6, Nb=4, density=0.05, dt=5e-3, Rm=1.4, Nmax=4000, trap=True, a_ho=[1.0])
+    cfg, S = SystemConfig(**kw), System(**kw)
+    VT, WF = oracle.tables(S)
+    assert abs(S.rcut - 30.0) < 1e-12
+    rng = np.random.default_rng(67)
+    W, n = 2, 400
+    Paths = (np.arange(S.Np) - 2.5)[None, None, :, None] * 17.0 + rng.uniform(-3.0, 3.0, (W, S.M, S.Np, 1))   # spans 85 a_ho: pairs up to 2.8 rcut apart
+    w = rng.integers(0, W, n).astype(np.int32)
+    ip = rng.integers(1, S.Np + 1, n).astype(np.int32)
+    ib = rng.integers(0, S.M, n).astype(np.int32)
+    xold = Paths[w, ib, ip - 1].copy()
+    xnew = rng.uniform(-60.0, 60.0, xold.shape)
+    want = oracle.delta_action_batch(S, WF, VT, Paths, w, ip, ib, xnew, xold)
+    fin = np.isfinite(want)
+    assert fin.sum() > n // 2
+    with gpu_lib.PigsContext(cfg, VT, WF, n_walkers=W) as ctx:
+        ctx.upload_all(Paths)
+        for v in (0, 1, 2, 14):
+            ctx.set_tuning("k1_variant", v)
+            got = ctx.delta_action_batch(w, ip, ib, xnew, xold)
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), v
+            assert np.all(np.abs(got - want)[fin] <= 1e-10 * np.abs(want[fin]) + 1e-9), (v, np.max(np.abs(got - want)[fin]))
+        E, Ec, Ep = ctx.therm_energy_batch()
+        le = ctx.local_energy_batch(0)
+    for k in range(W):
+        te = np.array(oracle.therm_energy(S, VT, Paths[k]))
+        if np.all(np.isfinite(te)):
+            assert np.all(np.abs(np.array([E[k], Ec[k], Ep[k]]) - te) <= 1e-10 * np.abs(te).max()), k
+        lo = np.array(oracle.local_energy(S, WF, VT, Paths[k][0]))
+        if np.all(np.isfinite(lo)):
+            assert np.all(np.abs(np.array([le[0][k], le[1][k], le[2][k]]) - lo) <= 1e-10 * (abs(lo[1]) + abs(lo[2]))), k
