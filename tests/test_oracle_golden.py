@@ -137,3 +137,30 @@ def test_mixed_estimator_is_ill_conditioned_at_one_ulp(oracle):
             worst = np.maximum(worst, np.abs(np.array(oracle.local_energy(S, WF, VT, R2)) - e0) / scale)
     assert worst[2] < 1e-13                                   # the potential energy is well conditioned
     assert MIXED_TOL < worst[0] < 2e-9 and MIXED_TOL < worst[1] < 2e-9, worst      # one ulp already breaks the contract
+
+
+def test_interpolate_beyond_the_table_is_clamped_not_out_of_bounds(oracle):
+    """interpolate.f90 reads F(ix+1) for any x; beyond the table's last cell (a trapped system's pair farther apart than
+    rcut: no cutoff there) that is out of bounds -- undefined in the reference.  The oracle clamps the cell index as the
+    product does: inside the table nothing changes, beyond it the last cell's values are used with the
+    unclamped offsets, and nothing behind the array is read (the sentinel stays unread)."""
+    N, dx = 50, 0.1
+    rng = np.random.default_rng(16)
+    F = rng.normal(size=N + 2)
+    G = np.concatenate([F, np.full(64, np.nan)])                 # a table followed by poison
+    for opt in (0, 1, 2):
+        for x in (0.31, 2.5, 4.89, N * dx - 1e-9):               # inside: same value with or without what lies behind the table
+            assert oracle.interpolate(opt, N, dx, F, x) == oracle.interpolate(opt, N, dx, G, x)
+        for x in (N * dx + 0.03, 7.77, 123.456):                 # beyond: finite, from the last cell
+            v = oracle.interpolate(opt, N, dx, G, x)
+            assert np.isfinite(v)
+            ix = int(x / dx) + 1
+            a1 = x - (ix - 1) * dx
+            a2 = dx - a1
+            i = N
+            if opt == 0:
+                want = (a1 * F[i] + a2 * F[i - 1]) / dx
+            else:
+                fb, fc, fa = (a1 * F[i - 1] + a2 * F[i - 2]) / dx, (a1 * F[i] + a2 * F[i - 1]) / dx, (a1 * F[i + 1] + a2 * F[i]) / dx
+                want = 0.5 * (fa - fb) / dx if opt == 1 else (fa - 2.0 * fc + fb) / (dx * dx)
+            assert v == want, (opt, x, v, want)
