@@ -508,6 +508,57 @@ def main():
                             "per_step": launch_stats([1e3 * t for t in ts2]), "note": "moves only; four walkers per CU"}
             finally:
                 ctx2.close()
+        # The same walkers as TWO shards of W/2 on this one GPU (the front end's `n_gpus = 2, same_device = T`; tuning key
+        # "cm_shared"): the shards' TranslateChain kernels are chained device-wide and run on the CUs the other shard's
+        # bisection phase leaves idle (H = 3 CUs per walker next to 64 sweeping walkers) -- a staggered schedule.  Steps are
+        # queued without a synchronisation in between (each shard has its own host thread in the front end); moves only,
+        # from the main leg's current worldlines.  Reported next to `moves_only`, which stays the one-context figure.
+        mc_two = None
+        if world == 1 and W % 2 == 0 and W >= 2:
+            n_cu = torch.cuda.get_device_properties(local).multi_processor_count
+            Hs = max(1, min(4, (n_cu - W // 2) // (W // 2)))
+            P_now = ctx.download_all()
+
+            def run_groups(groups):
+                """nmc MC steps (after two warm-up steps) of the walkers in `groups`, one context per group: seconds per step"""
+                cl = []
+                try:
+                    for lo, hi in groups:
+                        cs = api.PigsContext(cfg, VT, WF, n_walkers=hi - lo, device_id=local)
+                        cl.append(cs)
+                        cs.upload_all(P_now[lo:hi])
+                        cs.sampler_init(Nlev=mcfg.Nlev, Nstag=mcfg.Nstag, CMFreq=1, Lstag=min(32, args.nb), delta_cm=mcfg.delta_cm_eff)
+                        if len(groups) > 1:
+                            cs.set_tuning("cm_shared", 1)
+                            cs.set_tuning("cm_split", Hs)
+                        else:
+                            cs.set_tuning("cm_exclusive", 1)       # the main context is idle during this leg
+                        for w in range(lo, hi):
+                            cs.sampler_seed(w - lo, 7000 + w)
+                    for q in range(2):
+                        for cs in cl:
+                            cs.sampler_step(1 + q)
+                    for cs in cl:
+                        cs.sync()
+                    t = time.perf_counter()
+                    for q in range(nmc):
+                        for cs in cl:
+                            cs.sampler_step(3 + q)
+                    for cs in cl:
+                        cs.sync()
+                    return (time.perf_counter() - t) / nmc
+                finally:
+                    for cs in cl:
+                        cs.close()
+            t_one = run_groups([(0, W)])
+            t_two = run_groups([(0, W // 2), (W // 2, W)])
+            del P_now
+            mc_two = {"walkers": W, "shards": 2, "cm_split": Hs, "walker_sweeps_per_s": W / t_two, "ms_per_mc_step": 1e3 * t_two,
+                      "one_context_same_start": {"walker_sweeps_per_s": W / t_one, "ms_per_mc_step": 1e3 * t_one},
+                      "mc_steps_timed": nmc,
+                      "note": "two contexts of W/2 walkers on this GPU, TranslateChain kernels chained device-wide (cm_shared): one "
+                              "shard's TranslateChain beside the other's bisection phase; steps queued back to back; "
+                              "`one_context_same_start`: the same walkers, seeds and steps in ONE context, timed the same way"}
         # BASELINE config 5's shape on this GPU: N=256, 321 beads, dipolar r^-3 table, worm sector with the stock CWorm = 0.5,
         # Nobdm = 10, swapping, two partial waves -- divergent worm control flow next to the long-tail pair kernel.  Moves only.
         mc_c5 = None
@@ -567,7 +618,7 @@ def main():
                              "per_step": launch_stats([1e3 * t for t in ts_moves]),
                              "first_steps": {"ms_per_mc_step": 1e3 * first_steps_s, "walker_sweeps_per_s": W / first_steps_s,
                                              "note": "steps 2-4 after one warm-up step, as round 2 timed them (this rank only)"}},
-              "walkers_per_gpu": W, "moves_only_large": mc_large, "config5": mc_c5,
+              "walkers_per_gpu": W, "moves_only_two_shards": mc_two, "moves_only_large": mc_large, "config5": mc_c5,
               "kernels": "pigs::k_sweep (open/close attempt; bisection + worm moves) around pigs::k_cm (TranslateChain on 2 CUs per "
                          "walker while CUs >= 2 x walkers) + k_local_energy x2, k_slice_energy, "
                          "k_therm_combine, k_structure per step",

@@ -93,6 +93,11 @@ int pigs_stream(pigs_ctx *ctx, void **hip_stream);
  *      PROCESSES crowding one chip: set 1 there) gives up after seconds and the next pigs_sync returns PIGS_ERR_HIP.
  *   "cm_exclusive": 1 = the caller vouches that the process's other contexts on this device are idle while this one
  *      samples, so H > 1 stays allowed although it is not the only live context (bench.py's extra legs).
+ *   "cm_shared": 1 = several contexts of this process sample on this device AT ONCE (walker shards on one GPU): their
+ *      TranslateChain kernels are chained through one event per device, never two at a time, so that H > 1 stays safe
+ *      next to the other contexts' sweep kernels -- set "cm_split" so that H x walkers + the others' walkers <= CUs
+ *      (two contexts of 64 walkers on 256 CUs: 3).  The shards then run staggered: one's TranslateChain on the CUs the
+ *      other's bisection phase leaves idle.
  *   "cm_fault": TEST ONLY -- forces the time-out of that exchange once. */
 int pigs_set_tuning(pigs_ctx *ctx, const char *key, int32_t value);
 /* Device self-test: the kernels' short exact division / sqrt forms against IEEE `/` and sqrt()

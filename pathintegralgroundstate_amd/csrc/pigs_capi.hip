@@ -129,6 +129,7 @@ struct pigs_ctx {
     // TranslateChain by several workgroups per walker (pigs_cm.hip): -1 as many as fit (default), 0 off, H >= 1 at most H
     int         cm_split = -1;
     bool        cm_exclusive = false;       // the caller vouches that no other context's kernels run on this device meanwhile
+    bool        cm_shared = false;          // several contexts of this process sample on this device at once: see g_cm_gate
     unsigned long long *d_xch = nullptr;    // exchange buffer of the cooperating workgroups
     int        *h_cm_err = nullptr;         // (pinned, device-visible) set by a workgroup whose partner never answered
     unsigned int cm_seq = 1;                // sequence tags of the exchange: advanced by every launch
@@ -150,6 +151,16 @@ struct pigs_ctx {
 // live contexts per device of this process: the TranslateChain helpers (pigs_cm.hip) assume that the walkers of ONE
 // context have the chip to themselves
 static std::atomic<int> g_live_ctx[64];
+static std::atomic<int> g_ctx_serial[64];   // contexts ever created per device (stream priority: see pigs_ctx_create)
+
+// Several sampling contexts on ONE device (walker shards of the front end with `same_device`, tuning key "cm_shared"): the
+// TranslateChain kernels of all of them are chained through one event per device, so that never two of them run at once --
+// their workgroups wait for each other and must all be resident; next to the OTHER contexts' sweep kernels (one CU per
+// walker, finite) they are, as long as H x walkers of the launching context + the walkers of the others <= CUs (the caller
+// sets "cm_split" accordingly: 2 contexts x 64 walkers on 256 CUs -> H = 3).  The effect is a staggered schedule: one
+// shard's TranslateChain on the CUs the other shard's bisection phase leaves idle.
+static std::mutex g_cm_mutex[64];
+static hipEvent_t g_cm_gate[64];
 
 static int check_ctx(pigs_ctx *c)
 {
@@ -242,7 +253,18 @@ int pigs_ctx_create(const pigs_params *p, const double *VTable, const double *Lo
 
     int rc = PIGS_OK;
     do {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        {
+            // Contexts on one device alternate between the normal and the high stream priority: the runtime maps streams onto
+            // a few hardware queues PER PRIORITY (GPU_MAX_HW_QUEUES = 4 by default, shared with every other stream of the
+            // process), and two sampling shards whose streams land on one hardware queue run one after the other instead of
+            // side by side (round 3: bench.py's two-shard leg at 77 instead of 38.5 ms per MC step).  Different priorities
+            // are different queues for certain; with CUs to spare the priority itself decides nothing.
+            int least = 0, greatest = 0;
+            const int serial = g_ctx_serial[device_id & 63].fetch_add(1);
+            if ((serial & 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+                if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+            } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
+        }
         const size_t tb = (size_t)(p->Nmax + 2) * sizeof(double);
         if (hipMalloc((void **)&c->d_VT, tb) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
         if (hipMalloc((void **)&c->d_WF, tb) != hipSuccess) { rc = PIGS_ERR_HIP; break; }
@@ -360,6 +382,10 @@ int pigs_set_tuning(pigs_ctx *c, const char *key, int32_t value)
     }
     if (!strcmp(key, "cm_fault")) {             // TEST ONLY: force the time-out path of the TranslateChain exchange (pigs_cm.hip)
         c->sweep.cm_fault = (c->sweep.cm_fault & ~1) | (value != 0 ? 1 : 0);
+        return PIGS_OK;
+    }
+    if (!strcmp(key, "cm_shared")) {            // 1: several contexts of this process sample on this device at once (see g_cm_gate);
+        c->cm_shared = value != 0;              // set "cm_split" so that H x walkers + the other contexts' walkers <= CUs
         return PIGS_OK;
     }
     if (!strcmp(key, "cm_exclusive")) {         // 1: other contexts of this process on the device are idle while this one samples
@@ -832,7 +858,7 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
         // cooperating workgroups wait for each other: only while this context has the chip to itself.  One workgroup per
         // walker (H = 1) exchanges nothing and is still the faster TranslateChain (sixteen waves on the LDS table image:
         // 46.8 -> 44.8 ms per MC step at 256 walkers, 95 -> 74 ms at 512, where the sweep kernel runs its 4-wave form)
-        if (H > 1 && g_live_ctx[c->device & 63].load() != 1 && !c->cm_exclusive) H = 1;
+        if (H > 1 && g_live_ctx[c->device & 63].load() != 1 && !c->cm_exclusive && !c->cm_shared) H = 1;
         // a lowered H means longer bead ranges per workgroup: 321 beads fit two workgroups per walker but not one (rows, LDS)
         // -- then TranslateChain stays inside the sweep kernel (round 3: the BASELINE-config-5 leg of bench.py next to a
         // second live context, and the sharded front end on one GPU, failed here with "invalid argument")
@@ -852,8 +878,19 @@ int pigs_sampler_step(pigs_ctx *c, int32_t istep)
                             c->d_worm, c->d_evlog, c->d_nrho, c->d_dklog, c->stream));
         int *d_err = nullptr;
         HIPCHK(hipHostGetDevicePointer((void **)&d_err, c->h_cm_err, 0));
-        const hipError_t e = launch_cm(c->P, sp, H, c->cm_seq, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
-                                       c->d_worm, c->d_xch, d_err, c->stream);
+        hipError_t e = hipSuccess;
+        if (c->cm_shared && H > 1) {
+            std::lock_guard<std::mutex> lk(g_cm_mutex[c->device & 63]);
+            hipEvent_t &gate = g_cm_gate[c->device & 63];
+            if (!gate) e = hipEventCreateWithFlags(&gate, hipEventDisableTiming);
+            else       e = hipStreamWaitEvent(c->stream, gate, 0);           // the device's previous TranslateChain kernel, whoever launched it
+            if (e == hipSuccess) e = launch_cm(c->P, sp, H, c->cm_seq, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                                               c->d_worm, c->d_xch, d_err, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(gate, c->stream);
+        } else {
+            e = launch_cm(c->P, sp, H, c->cm_seq, c->d_paths, c->d_VTimg, c->d_WF, c->d_rng, c->d_counters,
+                          c->d_worm, c->d_xch, d_err, c->stream);
+        }
         HIPCHK(e);
         c->cm_seq += (unsigned int)c->P.Np + 1;
         sp.do_cm = 0;
@@ -1289,8 +1326,18 @@ int pigs_comm_init_all(pigs_ctx **ctxs, int32_t nranks)
         g->n = nranks;
         g->slot.resize(nranks);
         // (several contexts share one chip here: one workgroup per walker in pigs_cm.hip -- cooperating workgroups assume
-        // that the walkers of ONE context have the chip to themselves)
-        for (int i = 0; i < nranks; ++i) { ctxs[i]->hgroup = g; ctxs[i]->hrank = i; ctxs[i]->cm_split = 1; }
+        // that the walkers of ONE context have the chip to themselves -- except for TWO shards: their TranslateChain kernels
+        // are chained device-wide (g_cm_gate) and take the CUs the other shard's sweep kernel leaves, H x own walkers +
+        // the other's walkers <= CUs.  The shards then run staggered -- 38.5 instead of 39.9 ms per MC step of 2 x 64
+        // walkers at N=256, scripts/k6_stagger.py.  More than two shards would share the process's four hardware queues.)
+        for (int i = 0; i < nranks; ++i) {
+            ctxs[i]->hgroup = g; ctxs[i]->hrank = i; ctxs[i]->cm_split = 1;
+            if (nranks == 2 && ctxs[i]->n_walkers > 0) {
+                int H = (ctxs[i]->n_cu - ctxs[1 - i]->n_walkers) / ctxs[i]->n_walkers;
+                H = H > 4 ? 4 : H;
+                if (H >= 2) { ctxs[i]->cm_split = H; ctxs[i]->cm_shared = true; }
+            }
+        }
         return PIGS_OK;
     }
     const char *err = pigs_comm_create_all(comms.data(), nranks, devs.data());

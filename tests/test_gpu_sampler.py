@@ -523,3 +523,44 @@ def test_translate_chain_kernel_steps_aside_when_the_chain_does_not_fit_one_work
     assert res[0][1][:, 14].min() > 0
     for cm in (1, 2):
         assert same_bits(res[cm][0], res[0][0]) and np.array_equal(res[cm][1], res[0][1]), cm
+
+
+def test_two_sampling_contexts_on_one_device_share_it_through_the_translate_chain_gate(gpu_lib, oracle):
+    """Two walker shards sampling on ONE GPU at once (tuning key "cm_shared"; the front end's `n_gpus = 2, same_device = T`):
+    their TranslateChain kernels -- cooperating workgroups that must all be resident -- are chained through one event per
+    device, each on H = 3 CUs per walker next to the other shard's sweep kernel, steps queued alternately without a
+    synchronisation in between.  Every walker's trajectory is the one a single context of all walkers gives (bit for bit);
+    scripts/k6_stagger.py times the staggered schedule this produces at the BASELINE size (38.5 against 39.9 ms per MC step)."""
+    from oracle.pyoracle import System
+    kw = dict(dim=3, Np=24, Nb=20, density=0.3, dt=5e-3, Rm=1.2)
+    cfg = SystemConfig(Nlev=3, Nstag=2, Lstag=8, CMFreq=1, delta_cm=0.3, **kw)
+    S = System(**kw)
+    VT, WF = gpu_lib.build_tables(cfg)
+    W, nstep = 12, 6
+    start = [oracle.init_path(S, 300 + w) for w in range(W)]
+
+    def run(groups, shared):
+        ctxs = []
+        for lo, hi in groups:
+            c = gpu_lib.PigsContext(cfg, VT, WF, n_walkers=hi - lo)
+            c.sampler_init()
+            if shared:
+                c.set_tuning("cm_shared", 1)
+                c.set_tuning("cm_split", 3)
+            for w in range(lo, hi):
+                c.sampler_set_rng(w - lo, start[w][1].mti, np.array(start[w][1].mt[:], np.uint32))
+            c.upload_all(np.stack([start[w][0] for w in range(lo, hi)]))
+            ctxs.append(c)
+        for istep in range(1, nstep + 1):
+            for c in ctxs:
+                c.sampler_step(istep)
+        out = np.concatenate([c.download_all() for c in ctxs])
+        cnt = np.concatenate([c.sampler_counters16() for c in ctxs])
+        for c in ctxs:
+            c.close()
+        return out, cnt
+
+    one = run([(0, W)], False)
+    two = run([(0, W // 2), (W // 2, W)], True)
+    assert one[1][:, 14].min() > 0                                   # TranslateChain moves were tried
+    assert same_bits(one[0], two[0]) and np.array_equal(one[1], two[1])
